@@ -1,0 +1,119 @@
+/*
+ * CPU oracle for the AD-Census matcher path -- TEST INFRASTRUCTURE ONLY.
+ *
+ * This is a plain-C restatement of the reference algorithm
+ * (final_version_project/Stereo_Matching/ADCensus_CUDA/, abbreviated ADC/ below).  It is the
+ * checker the parity tests compare the HIP path against and the CPU baseline that bench.py
+ * times.  Nothing in the shipped library links, loads or calls it.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or recorded outputs, and its
+ * CUDA/MSVC/OpenCV sources cannot be built in this image, so this restatement is pinned only by
+ * hand-checkable known-answer tests (tests/test_oracle_kat.py) and by the Middlebury 2003
+ * ground truth through the reference's own bad-2.0 definition (ADC/performance_eval.cpp:218-253).
+ *
+ * Canonical semantics: where the shipped CUDA code is racy or plainly broken (in-place updates
+ * read by other threads, a stray `return`, unparenthesised MIN/MAX macros, a float passed to
+ * memset) the oracle implements what the code evidently intends: every in-place pass reads a
+ * snapshot of its input, min/max are true min/max, sentinels are Large_Float, all four scanline
+ * directions run, and the runtime disparity range is used everywhere.
+ *
+ * Layouts are the reference's: images BGR-interleaved u8[H][W][3]; volumes f32[H][W][D]
+ * (D = max_disparity - min_disparity, disparity fastest); census u64[H][W]; arms 4 x u8 per pixel
+ * in the order {left,right,top,bottom}; support counts u16[H][W]; invalid disparity = +inf.
+ */
+#ifndef ADCENSUS_ORACLE_H_
+#define ADCENSUS_ORACLE_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Field-for-field ADCensusOption (ADC/adcensus_types.h:64-96) with fixed-width types. */
+typedef struct orc_option {
+    int32_t min_disparity;
+    int32_t max_disparity;
+    int32_t lambda_ad;
+    int32_t lambda_census;
+    int32_t cross_L1;
+    int32_t cross_L2;
+    int32_t cross_t1;
+    int32_t cross_t2;
+    float   so_p1;
+    float   so_p2;
+    int32_t so_tso;
+    int32_t irv_ts;
+    float   irv_th;
+    float   lrcheck_thres;
+    uint8_t do_lr_check;
+    uint8_t do_filling;
+    uint8_t do_discontinuity_adjustment;
+    uint8_t reserved_;
+} orc_option;
+
+/* Optional taps filled by orc_match (any pointer may be NULL). */
+typedef struct orc_taps {
+    uint8_t  *gray_left, *gray_right;          /* u8[H][W]                                  */
+    uint64_t *census_left, *census_right;      /* u64[H][W]                                 */
+    float    *cost_init;                       /* f32[H][W][D]                              */
+    uint8_t  *arms;                            /* u8[H][W][4]                               */
+    uint16_t *sup_count_h, *sup_count_v;       /* u16[H][W]                                 */
+    float    *cost_aggr;                       /* f32[H][W][D] after the 4 iterations       */
+    float    *cost_scan;                       /* f32[H][W][D] after the 4 scanline passes  */
+    float    *cost_scan_aux;                   /* f32[H][W][D] the other ping-pong buffer   */
+    float    *disp_left_wta, *disp_right_wta;  /* f32[H][W]                                 */
+    float    *disp_outlier;                    /* after outlier detection                   */
+    uint8_t  *mask_occ, *mask_mis;             /* after outlier detection                   */
+    float    *disp_voting;                     /* after iterative region voting             */
+    uint8_t  *mask_occ_voting, *mask_mis_voting;
+    float    *disp_interp;                     /* after proper interpolation                */
+    uint8_t  *edge_mask;                       /* sobel mask                                */
+    float    *disp_edge;                       /* after discontinuity adjustment            */
+} orc_taps;
+
+void orc_default_option(orc_option *o);
+
+void orc_gray(const uint8_t *bgr, int W, int H, uint8_t *gray);
+void orc_census(const uint8_t *gray, int W, int H, uint64_t *census);
+void orc_cost_init(const uint8_t *L, const uint8_t *R, const uint64_t *cenL, const uint64_t *cenR,
+                   int W, int H, int dmin, int dmax, int lambda_ad, int lambda_census, float *cost);
+void orc_build_arms(const uint8_t *L, int W, int H, int L1, int L2, int t1, int t2, uint8_t *arms);
+void orc_sup_counts(const uint8_t *arms, int W, int H, uint16_t *cnt_h, uint16_t *cnt_v);
+void orc_aggregate(float *cost, const uint8_t *arms, const uint16_t *cnt_h, const uint16_t *cnt_v,
+                   int W, int H, int D, int iters);
+void orc_scanline_pass(const uint8_t *L, const uint8_t *R, const float *src, float *dst,
+                       int W, int H, int dmin, int dmax, float p1, float p2, int tso,
+                       int vertical, int forward);
+void orc_scanline(const uint8_t *L, const uint8_t *R, float *aggr, float *init,
+                  int W, int H, int dmin, int dmax, float p1, float p2, int tso);
+void orc_wta_left(const float *cost, int W, int H, int dmin, int dmax, float *disp);
+void orc_wta_right(const float *cost, int W, int H, int dmin, int dmax, float *disp);
+void orc_outlier(const float *disp_l, const float *disp_r, int W, int H, float thres,
+                 float *disp_out, uint8_t *occ, uint8_t *mis);
+void orc_region_voting_pass(const float *disp_in, float *disp_out, uint8_t *mask,
+                            const uint8_t *arms, int W, int H, int dmin, int dmax,
+                            int tau_s, float tau_h);
+void orc_interpolate(const uint8_t *L, const float *disp_in, float *disp_out,
+                     const uint8_t *occ, const uint8_t *mis, int W, int H, int dmax);
+void orc_edge_detect(const float *disp, int W, int H, float thres, uint8_t *edge);
+void orc_edge_adjust(const float *disp_in, float *disp_out, const float *cost, const uint8_t *edge,
+                     int W, int H, int dmin, int dmax);
+void orc_median3(const float *in, float *out, int W, int H);
+
+/* Whole pipeline = ADCensusStereo::Match (ADC/ADCensusStereo.cu:64-145). Returns 0 on success. */
+int orc_match(const uint8_t *L, const uint8_t *R, int W, int H, const orc_option *opt,
+              float *disp_left, const orc_taps *taps);
+
+/* bad-delta fraction as PerformanceEval0103 (ADC/performance_eval.cpp:218-253): GT==0 skipped,
+ * invalid estimate counts as 0, denominator W*H. Also returns RMS through *rms if non-NULL. */
+double orc_bad_fraction(const float *disp, const uint8_t *gt, int W, int H, float gt_scale,
+                        float delta, double *rms);
+
+int orc_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
