@@ -1,0 +1,8 @@
+"""MI355X-native AD-Census matcher: host-side mirror of the reference interface over the C-ABI.
+
+The directory name carries a hyphen, so import it with
+    importlib.import_module("stereo-matching_amd")
+(with the repository root on sys.path).
+"""
+from .adcensus import (ADCensusOption, ADCensusStereo, BUFFERS, EXPORTS, LIB_PATH, STAGES, lib,  # noqa: F401
+                       match_batch)

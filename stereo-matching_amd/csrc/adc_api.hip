@@ -1,0 +1,570 @@
+// C-ABI of libadcensus_hip.so: handle life cycle, the match pipeline (all device-resident, one
+// stream, no allocation after adc_initialize), taps, profiling and the frame-sharded batch call.
+// Mirrors ADCensusStereo (ADC/ADCensusStereo.h:9-90, ADC/ADCensusStereo.cu:16-157;
+// ADC/ = final_version_project/Stereo_Matching/ADCensus_CUDA/).
+#include "adc_common.h"
+#include "../../include/adcensus.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace adc;
+
+namespace {
+thread_local std::string g_thread_error;
+enum { N_AGG_PASSES = 8, N_EVENTS = ADC_STAGE_COUNT_ };  // stage boundaries: PRE|COST|AGGR|SCAN|WTA|REFINE|end
+}
+
+struct adc_handle {
+    int device = 0;
+    bool initialized = false;
+    bool debug_taps = false;
+    bool profiling = false;
+    bool have_times = false;
+    int agg_variant = 0;
+    adc_option opt{};
+    Geom g{};
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<void *> dev_allocs;
+    std::vector<void *> host_allocs;
+    std::vector<hipEvent_t> events;
+
+    // images
+    uint8_t *d_bgr_l = nullptr, *d_bgr_r = nullptr;
+    uint8_t *h_bgr_l = nullptr, *h_bgr_r = nullptr;  // pinned staging
+    float *h_disp = nullptr;
+    Planes pl{};
+    // volumes: B holds the initial cost, then every even result; A is the other ping-pong buffer
+    float *vol_a = nullptr, *vol_b = nullptr;
+    float *snap_init = nullptr, *snap_aggr = nullptr;
+    // tables
+    float *lut_ad = nullptr, *lut_cen = nullptr;
+    double *ray_dy = nullptr, *ray_dx = nullptr;
+    int ray_len = 0;
+    ScanParams sp{};
+    // disparity maps and masks
+    float *disp_a = nullptr, *disp_b = nullptr, *disp_r = nullptr, *disp_final = nullptr;
+    float *cur_disp = nullptr;        // which of disp_a/disp_b holds the map after edge adjustment
+    uint8_t *occ = nullptr, *mis = nullptr, *edge = nullptr;
+    uint32_t *list_mis = nullptr, *list_occ = nullptr, *counters = nullptr;
+    float *newval = nullptr;
+    // debug snapshots
+    float *snap_wta_l = nullptr, *snap_outlier = nullptr, *snap_voting = nullptr, *snap_interp = nullptr;
+    uint8_t *snap_occ = nullptr, *snap_mis = nullptr;
+    uint64_t *tap_u64 = nullptr;      // census widening scratch
+    float times[ADC_STAGE_COUNT_] = {0};
+
+    int fail(int code, const std::string &msg) {
+        err = msg;
+        return code;
+    }
+    int fail_hip(const char *what, hipError_t e) {
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        return ADC_ERR_HIP;
+    }
+};
+
+#define HIPCHK(h, call)                                       \
+    do {                                                      \
+        hipError_t e_ = (call);                               \
+        if (e_ != hipSuccess) return (h)->fail_hip(#call, e_); \
+    } while (0)
+
+namespace {
+
+template <typename T>
+int dev_alloc(adc_handle *h, T **p, size_t count) {
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, count * sizeof(T) + 256);
+    if (e != hipSuccess) {
+        h->err = std::string("hipMalloc: ") + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? ADC_ERR_NOMEM : ADC_ERR_HIP;
+    }
+    h->dev_allocs.push_back(q);
+    *p = static_cast<T *>(q);
+    return ADC_OK;
+}
+template <typename T>
+int host_alloc(adc_handle *h, T **p, size_t count) {
+    void *q = nullptr;
+    hipError_t e = hipHostMalloc(&q, count * sizeof(T), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        h->err = std::string("hipHostMalloc: ") + hipGetErrorString(e);
+        return ADC_ERR_NOMEM;
+    }
+    h->host_allocs.push_back(q);
+    *p = static_cast<T *>(q);
+    return ADC_OK;
+}
+
+void release(adc_handle *h) {
+    if (h->stream) hipStreamSynchronize(h->stream);
+    for (void *p : h->dev_allocs) hipFree(p);
+    for (void *p : h->host_allocs) hipHostFree(p);
+    for (hipEvent_t e : h->events) hipEventDestroy(e);
+    h->dev_allocs.clear();
+    h->host_allocs.clear();
+    h->events.clear();
+    if (h->stream) { hipStreamDestroy(h->stream); h->stream = nullptr; }
+    h->snap_init = h->snap_aggr = nullptr;
+    h->initialized = false;
+    h->have_times = false;
+}
+
+int alloc_debug(adc_handle *h) {
+    if (h->snap_init) return ADC_OK;
+    const size_t npx = (size_t)h->g.W * h->g.H, nvol = npx * h->g.Dp;
+    int rc;
+    if ((rc = dev_alloc(h, &h->snap_init, nvol))) return rc;
+    if ((rc = dev_alloc(h, &h->snap_aggr, nvol))) return rc;
+    if ((rc = dev_alloc(h, &h->snap_wta_l, npx))) return rc;
+    if ((rc = dev_alloc(h, &h->snap_outlier, npx))) return rc;
+    if ((rc = dev_alloc(h, &h->snap_voting, npx))) return rc;
+    if ((rc = dev_alloc(h, &h->snap_interp, npx))) return rc;
+    if ((rc = dev_alloc(h, &h->snap_occ, npx))) return rc;
+    if ((rc = dev_alloc(h, &h->snap_mis, npx))) return rc;
+    return ADC_OK;
+}
+
+int do_initialize(adc_handle *h, int32_t W, int32_t H, const adc_option *opt) {
+    if (!opt) return h->fail(ADC_ERR_ARG, "adc_initialize: option is null");
+    // ADCensusStereo::Initialize rejects w,h <= 0 and an empty disparity range (ADC/ADCensusStereo.cu:26-35)
+    if (W <= 0 || H <= 0) return h->fail(ADC_ERR_ARG, "adc_initialize: width and height must be positive");
+    const long long D64 = (long long)opt->max_disparity - (long long)opt->min_disparity;
+    if (D64 <= 0) return h->fail(ADC_ERR_ARG, "adc_initialize: max_disparity must exceed min_disparity");
+    if (D64 > 1024) return h->fail(ADC_ERR_UNSUPPORTED, "adc_initialize: more than 1024 disparities not supported");
+    if (opt->lambda_ad <= 0 || opt->lambda_census <= 0)
+        return h->fail(ADC_ERR_ARG, "adc_initialize: lambda_ad and lambda_census must be positive");
+    if ((unsigned long long)W * (unsigned long long)H >= (1ull << 31))
+        return h->fail(ADC_ERR_UNSUPPORTED, "adc_initialize: image larger than 2^31 pixels");
+    if (H > 65535 || W > 65535)
+        return h->fail(ADC_ERR_UNSUPPORTED, "adc_initialize: image side larger than 65535");
+
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->opt = *opt;
+    Geom &g = h->g;
+    g.W = W; g.H = H; g.dmin = opt->min_disparity; g.dmax = opt->max_disparity; g.D = (int)D64;
+    g.NV = 1;
+    while (64 * g.NV < g.D) g.NV *= 2;
+    g.Dp = ((g.D + g.NV - 1) / g.NV) * g.NV;
+
+    const size_t npx = (size_t)W * H, nvol = npx * g.Dp;
+    int rc;
+#define A(p, n) if ((rc = dev_alloc(h, &(p), (n)))) return rc
+    A(h->d_bgr_l, npx * 3); A(h->d_bgr_r, npx * 3);
+    A(h->pl.pix_l, npx); A(h->pl.pix_r, npx);
+    A(h->pl.gray_l, npx); A(h->pl.gray_r, npx);
+    A(h->pl.cen_l, npx); A(h->pl.cen_r, npx);
+    A(h->pl.step_l, npx); A(h->pl.step_r, npx);
+    A(h->pl.arms, npx); A(h->pl.cnt_h, npx); A(h->pl.cnt_v, npx);
+    A(h->vol_a, nvol); A(h->vol_b, nvol);
+    A(h->lut_ad, 768); A(h->lut_cen, 68);
+    A(h->disp_a, npx); A(h->disp_b, npx); A(h->disp_r, npx); A(h->disp_final, npx);
+    A(h->occ, npx); A(h->mis, npx); A(h->edge, npx);
+    A(h->list_mis, npx); A(h->list_occ, npx); A(h->counters, 4);
+    A(h->newval, 2 * npx);
+    A(h->tap_u64, npx);
+#undef A
+    if ((rc = host_alloc(h, &h->h_bgr_l, npx * 3))) return rc;
+    if ((rc = host_alloc(h, &h->h_bgr_r, npx * 3))) return rc;
+    if ((rc = host_alloc(h, &h->h_disp, npx))) return rc;
+    // padding columns of the volumes are never produced by the cost kernel; give them a defined value once
+    HIPCHK(h, hipMemsetAsync(h->vol_a, 0, nvol * sizeof(float), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->vol_b, 0, nvol * sizeof(float), h->stream));
+
+    // exp tables of the initial cost (ADC/cost_computor.cu:186,200-203): entry = expf of the float
+    // argument, taken as the correctly rounded (float)exp((double)arg).
+    {
+        std::vector<float> ad(768, 0.0f), cen(68, 0.0f);
+        for (int s = 0; s < 766; s++) {
+            const float a = (float)s / 3.0f;
+            const float arg = -a / (float)opt->lambda_ad;
+            ad[s] = (float)std::exp((double)arg);
+        }
+        for (int k = 0; k < 65; k++) {
+            const float arg = -(float)k / (float)opt->lambda_census;
+            cen[k] = (float)std::exp((double)arg);
+        }
+        HIPCHK(h, hipMemcpyAsync(h->lut_ad, ad.data(), 768 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->lut_cen, cen.data(), 68 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    // ray tables of the 16-direction search (ADC/multistep_refiner.cu:561-583, :642):
+    // ang += PI/16 with PI = 3.1415926f, accumulated in double; entries m*sin(ang), m*cos(ang).
+    {
+        const int maxlen = std::abs(opt->max_disparity) * 1;  // MaxSearchLengthTimes = 1 (ADC/config.h:24)
+        h->ray_len = maxlen > 1 ? maxlen : 1;
+        std::vector<double> dy((size_t)16 * h->ray_len, 0.0), dx((size_t)16 * h->ray_len, 0.0);
+        double ang = 0.0;
+        const float step = 3.1415926f / 16;
+        for (int s = 0; s < 16; s++) {
+            const double sa = std::sin(ang), ca = std::cos(ang);
+            for (int m = 0; m < h->ray_len; m++) {
+                dy[(size_t)s * h->ray_len + m] = (double)m * sa;
+                dx[(size_t)s * h->ray_len + m] = (double)m * ca;
+            }
+            ang += step;
+        }
+        if ((rc = dev_alloc(h, &h->ray_dy, dy.size()))) return rc;
+        if ((rc = dev_alloc(h, &h->ray_dx, dx.size()))) return rc;
+        HIPCHK(h, hipMemcpy(h->ray_dy, dy.data(), dy.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(h->ray_dx, dx.data(), dx.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    // penalty table (ADC/scanline_optimizer.cu:97-109)
+    h->sp.P1[0] = opt->so_p1; h->sp.P1[1] = opt->so_p1 / 4; h->sp.P1[2] = opt->so_p1 / 10;
+    h->sp.P2[0] = opt->so_p2; h->sp.P2[1] = opt->so_p2 / 4; h->sp.P2[2] = opt->so_p2 / 10;
+
+    h->events.resize(N_EVENTS);
+    for (auto &e : h->events) HIPCHK(h, hipEventCreate(&e));
+    if (h->debug_taps && (rc = alloc_debug(h))) return rc;
+    h->pl.bgr_l = h->d_bgr_l;
+    h->pl.bgr_r = h->d_bgr_r;
+    h->cur_disp = h->disp_a;
+    h->initialized = true;
+    h->err.clear();
+    return ADC_OK;
+}
+
+inline int max_arm_of(const adc_option &o) {
+    int cap = o.cross_L1 < 255 ? o.cross_L1 : 255;
+    return cap < 0 ? 0 : cap;
+}
+
+// Enqueue the whole pipeline on stream s. d_out receives the final map (device pointer).
+int enqueue_match(adc_handle *h, const uint8_t *d_l, const uint8_t *d_r, float *d_out, hipStream_t s) {
+    const Geom &g = h->g;
+    const adc_option &o = h->opt;
+    const size_t npx = (size_t)g.W * g.H, nvol = npx * g.Dp;
+    Planes pl = h->pl;
+    pl.bgr_l = d_l;
+    pl.bgr_r = d_r;
+    const bool prof = h->profiling;
+    auto mark = [&](int i) { if (prof) hipEventRecord(h->events[i], s); };
+    auto snap = [&](void *dst, const void *src, size_t bytes) {
+        if (h->debug_taps) hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s);
+    };
+
+    mark(ADC_STAGE_PRE);
+    launch_pack_gray(d_l, pl.pix_l, pl.gray_l, g.W, g.H, s);
+    launch_pack_gray(d_r, pl.pix_r, pl.gray_r, g.W, g.H, s);
+    launch_census(pl.gray_l, pl.cen_l, g.W, g.H, s);
+    launch_census(pl.gray_r, pl.cen_r, g.W, g.H, s);
+    launch_step_flags(pl.pix_l, pl.step_l, g.W, g.H, o.so_tso, s);
+    launch_step_flags(pl.pix_r, pl.step_r, g.W, g.H, o.so_tso, s);
+    launch_arms(pl.pix_l, pl.arms, g.W, g.H, o.cross_L1, o.cross_L2, o.cross_t1, o.cross_t2, s);
+    launch_sup_counts(pl.arms, pl.cnt_h, pl.cnt_v, g.W, g.H, s);
+
+    mark(ADC_STAGE_COST);
+    launch_cost_init(pl, g, h->lut_ad, h->lut_cen, h->vol_b, s);
+    snap(h->snap_init, h->vol_b, nvol * sizeof(float));
+
+    // CrossAggregator::Aggregate: 4 iterations, horizontal-first on even ones (ADC/cost_aggregator.cu:112,440-454)
+    mark(ADC_STAGE_AGGR);
+    const int cap = max_arm_of(o);
+    for (int it = 0; it < 4; it++) {
+        const bool hfirst = (it % 2) == 0;
+        launch_aggregate_pass(h->vol_b, h->vol_a, pl.arms, nullptr, g, hfirst ? 0 : 1, cap, h->agg_variant, s);
+        launch_aggregate_pass(h->vol_a, h->vol_b, pl.arms, hfirst ? pl.cnt_h : pl.cnt_v, g, hfirst ? 1 : 0, cap,
+                              h->agg_variant, s);
+    }
+    snap(h->snap_aggr, h->vol_b, nvol * sizeof(float));
+
+    // ScanlineOptimizer::Optimize pass order and ping-pong (ADC/scanline_optimizer.cu:380-447)
+    mark(ADC_STAGE_SCAN);
+    launch_scanline_pass(h->vol_b, h->vol_a, pl, g, h->sp, 0, 1, s);
+    launch_scanline_pass(h->vol_a, h->vol_b, pl, g, h->sp, 0, 0, s);
+    launch_scanline_pass(h->vol_b, h->vol_a, pl, g, h->sp, 1, 1, s);
+    launch_scanline_pass(h->vol_a, h->vol_b, pl, g, h->sp, 1, 0, s);
+
+    mark(ADC_STAGE_WTA);
+    launch_wta(h->vol_b, h->disp_a, h->disp_r, g, s);
+    snap(h->snap_wta_l, h->disp_a, npx * sizeof(float));
+
+    // MultiStepRefiner::Refine (ADC/multistep_refiner.cu:283-371)
+    mark(ADC_STAGE_REFINE);
+    float *cur = h->disp_a, *oth = h->disp_b;
+    if (o.do_lr_check) {
+        launch_outlier(cur, h->disp_r, oth, h->occ, h->mis, h->list_mis, h->list_occ, h->counters, g.W, g.H,
+                       o.lrcheck_thres, s);
+        std::swap(cur, oth);
+    } else {
+        launch_clear_masks(h->occ, h->mis, h->counters, npx, s);
+    }
+    snap(h->snap_outlier, cur, npx * sizeof(float));
+    snap(h->snap_occ, h->occ, npx);
+    snap(h->snap_mis, h->mis, npx);
+    if (o.do_filling) {  // drives both voting and interpolation (ADC/ADCensusStereo.cu:195-196)
+        for (int it = 0; it < 5; it++) {  // IterativeNums (ADC/config.h:46): mismatch pass, then occlusion pass
+            launch_region_voting_pass(cur, h->mis, h->list_mis, h->counters + 0, h->newval, pl.arms, g, o.irv_ts,
+                                      o.irv_th, s);
+            launch_region_voting_pass(cur, h->occ, h->list_occ, h->counters + 1, h->newval, pl.arms, g, o.irv_ts,
+                                      o.irv_th, s);
+        }
+    }
+    snap(h->snap_voting, cur, npx * sizeof(float));
+    if (o.do_filling) {
+        launch_interpolate(cur, h->occ, h->mis, h->list_mis, h->list_occ, h->counters, h->newval, pl.pix_l,
+                           h->ray_dy, h->ray_dx, g, h->ray_len, s);
+    }
+    snap(h->snap_interp, cur, npx * sizeof(float));
+    if (o.do_discontinuity_adjustment) {
+        launch_edge_detect(cur, h->edge, g.W, g.H, 5.0f, s);
+        launch_edge_adjust(cur, oth, h->vol_b, h->edge, g, s);
+        std::swap(cur, oth);
+    } else {
+        hipMemsetAsync(h->edge, 0, npx, s);
+    }
+    h->cur_disp = cur;
+    launch_median3(cur, h->disp_final, g.W, g.H, s);
+    if (d_out && d_out != h->disp_final)
+        hipMemcpyAsync(d_out, h->disp_final, npx * sizeof(float), hipMemcpyDeviceToDevice, s);
+    mark(ADC_STAGE_TOTAL);
+    h->have_times = prof;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return h->fail_hip("kernel launch", e);
+    return ADC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void adc_default_option(adc_option *o) {
+    if (!o) return;
+    std::memset(o, 0, sizeof(*o));
+    o->min_disparity = 0;
+    o->max_disparity = 64;
+    o->lambda_ad = 10;
+    o->lambda_census = 30;
+    o->cross_L1 = 34;
+    o->cross_L2 = 17;
+    o->cross_t1 = 20;
+    o->cross_t2 = 6;
+    o->so_p1 = 1.0f;
+    o->so_p2 = 3.0f;
+    o->so_tso = 15;
+    o->irv_ts = 20;
+    o->irv_th = 0.4f;
+    o->lrcheck_thres = 1.0f;
+    o->do_lr_check = 1;
+    o->do_filling = 1;
+    o->do_discontinuity_adjustment = 1;
+}
+
+adc_handle *adc_create(int device) {
+    adc_handle *h = new (std::nothrow) adc_handle();
+    if (!h) { g_thread_error = "adc_create: out of host memory"; return nullptr; }
+    h->device = device;
+    const char *v = std::getenv("ADC_AGG_VARIANT");
+    if (v) h->agg_variant = std::atoi(v);
+    return h;
+}
+
+void adc_destroy(adc_handle *h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    release(h);
+    delete h;
+}
+
+int adc_initialize(adc_handle *h, int32_t width, int32_t height, const adc_option *opt) {
+    if (!h) return ADC_ERR_ARG;
+    if (h->initialized || !h->dev_allocs.empty()) { hipSetDevice(h->device); release(h); }
+    int rc = do_initialize(h, width, height, opt);
+    if (rc != ADC_OK) { std::string keep = h->err; hipSetDevice(h->device); release(h); h->err = keep; }
+    return rc;
+}
+
+int adc_reset(adc_handle *h, int32_t width, int32_t height, const adc_option *opt) {
+    return adc_initialize(h, width, height, opt);
+}
+
+int adc_match_device(adc_handle *h, const uint8_t *d_left, const uint8_t *d_right, float *d_disp, void *stream) {
+    if (!h) return ADC_ERR_ARG;
+    if (!h->initialized) return h->fail(ADC_ERR_NOT_INIT, "adc_match_device: handle not initialised");
+    if (!d_left || !d_right || !d_disp) return h->fail(ADC_ERR_ARG, "adc_match_device: null pointer");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    return enqueue_match(h, d_left, d_right, d_disp, s);
+}
+
+int adc_match(adc_handle *h, const uint8_t *left, const uint8_t *right, float *disp) {
+    if (!h) return ADC_ERR_ARG;
+    if (!h->initialized) return h->fail(ADC_ERR_NOT_INIT, "adc_match: handle not initialised");
+    if (!left || !right || !disp) return h->fail(ADC_ERR_ARG, "adc_match: null pointer");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t npx = (size_t)h->g.W * h->g.H;
+    std::memcpy(h->h_bgr_l, left, npx * 3);
+    std::memcpy(h->h_bgr_r, right, npx * 3);
+    HIPCHK(h, hipMemcpyAsync(h->d_bgr_l, h->h_bgr_l, npx * 3, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_bgr_r, h->h_bgr_r, npx * 3, hipMemcpyHostToDevice, h->stream));
+    int rc = enqueue_match(h, h->d_bgr_l, h->d_bgr_r, h->disp_final, h->stream);
+    if (rc != ADC_OK) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->h_disp, h->disp_final, npx * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::memcpy(disp, h->h_disp, npx * sizeof(float));
+    return ADC_OK;
+}
+
+int adc_synchronize(adc_handle *h) {
+    if (!h) return ADC_ERR_ARG;
+    if (!h->initialized) return h->fail(ADC_ERR_NOT_INIT, "adc_synchronize: handle not initialised");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ADC_OK;
+}
+
+int adc_set_debug_taps(adc_handle *h, int enable) {
+    if (!h) return ADC_ERR_ARG;
+    h->debug_taps = enable != 0;
+    if (h->debug_taps && h->initialized) {
+        HIPCHK(h, hipSetDevice(h->device));
+        return alloc_debug(h);
+    }
+    return ADC_OK;
+}
+
+int adc_set_profiling(adc_handle *h, int enable) {
+    if (!h) return ADC_ERR_ARG;
+    h->profiling = enable != 0;
+    return ADC_OK;
+}
+
+int adc_stage_times(adc_handle *h, float *ms, int n) {
+    if (!h || !ms || n < 0) return ADC_ERR_ARG;
+    if (!h->initialized) return h->fail(ADC_ERR_NOT_INIT, "adc_stage_times: handle not initialised");
+    if (!h->have_times) return h->fail(ADC_ERR_ARG, "adc_stage_times: no profiled match has run");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipEventSynchronize(h->events[ADC_STAGE_TOTAL]));
+    for (int i = 0; i < ADC_STAGE_TOTAL; i++)
+        HIPCHK(h, hipEventElapsedTime(&h->times[i], h->events[i], h->events[i + 1]));
+    HIPCHK(h, hipEventElapsedTime(&h->times[ADC_STAGE_TOTAL], h->events[0], h->events[ADC_STAGE_TOTAL]));
+    for (int i = 0; i < n && i < ADC_STAGE_COUNT_; i++) ms[i] = h->times[i];
+    return ADC_OK;
+}
+
+int adc_aggr_kernel_stats(adc_handle *h, int *launches, float *total_ms) {
+    if (!h) return ADC_ERR_ARG;
+    float t[ADC_STAGE_COUNT_];
+    int rc = adc_stage_times(h, t, ADC_STAGE_COUNT_);
+    if (rc != ADC_OK) return rc;
+    if (launches) *launches = N_AGG_PASSES;
+    if (total_ms) *total_ms = t[ADC_STAGE_AGGR];
+    return ADC_OK;
+}
+
+size_t adc_buffer_bytes(adc_handle *h, adc_buffer_id id) {
+    if (!h || !h->initialized) return 0;
+    const size_t npx = (size_t)h->g.W * h->g.H;
+    switch (id) {
+        case ADC_BUF_GRAY_LEFT: case ADC_BUF_GRAY_RIGHT:
+        case ADC_BUF_MASK_OCC: case ADC_BUF_MASK_MIS: case ADC_BUF_MASK_OCC_VOTING: case ADC_BUF_MASK_MIS_VOTING:
+        case ADC_BUF_EDGE_MASK:
+            return npx;
+        case ADC_BUF_CENSUS_LEFT: case ADC_BUF_CENSUS_RIGHT: return npx * 8;
+        case ADC_BUF_ARMS: return npx * 4;
+        case ADC_BUF_SUP_COUNT_H: case ADC_BUF_SUP_COUNT_V: return npx * 2;
+        case ADC_BUF_COST_INIT: case ADC_BUF_COST_AGGR: case ADC_BUF_COST_SCAN: case ADC_BUF_COST_SCAN_AUX:
+            return npx * (size_t)h->g.D * 4;
+        case ADC_BUF_DISP_LEFT_WTA: case ADC_BUF_DISP_RIGHT_WTA: case ADC_BUF_DISP_OUTLIER:
+        case ADC_BUF_DISP_VOTING: case ADC_BUF_DISP_INTERP: case ADC_BUF_DISP_EDGE: case ADC_BUF_DISP_FINAL:
+            return npx * 4;
+        default: return 0;
+    }
+}
+
+int adc_get_buffer(adc_handle *h, adc_buffer_id id, void *dst, size_t bytes) {
+    if (!h) return ADC_ERR_ARG;
+    if (!h->initialized) return h->fail(ADC_ERR_NOT_INIT, "adc_get_buffer: handle not initialised");
+    const size_t need = adc_buffer_bytes(h, id);
+    if (!dst || need == 0 || bytes < need) return h->fail(ADC_ERR_ARG, "adc_get_buffer: bad id, null or short destination");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());  // a match may have been enqueued on a caller's stream
+    const size_t npx = (size_t)h->g.W * h->g.H;
+    const void *src = nullptr;
+    const float *vol = nullptr;
+    bool debug_only = false;
+    switch (id) {
+        case ADC_BUF_GRAY_LEFT: src = h->pl.gray_l; break;
+        case ADC_BUF_GRAY_RIGHT: src = h->pl.gray_r; break;
+        case ADC_BUF_CENSUS_LEFT:
+        case ADC_BUF_CENSUS_RIGHT:
+            launch_census_to_u64(id == ADC_BUF_CENSUS_LEFT ? h->pl.cen_l : h->pl.cen_r, h->tap_u64, npx, h->stream);
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            src = h->tap_u64;
+            break;
+        case ADC_BUF_ARMS: src = h->pl.arms; break;  // little-endian u32 = bytes {left,right,top,bottom}
+        case ADC_BUF_SUP_COUNT_H: src = h->pl.cnt_h; break;
+        case ADC_BUF_SUP_COUNT_V: src = h->pl.cnt_v; break;
+        case ADC_BUF_COST_INIT: vol = h->snap_init; debug_only = true; break;
+        case ADC_BUF_COST_AGGR: vol = h->snap_aggr; debug_only = true; break;
+        case ADC_BUF_COST_SCAN: vol = h->vol_b; break;
+        case ADC_BUF_COST_SCAN_AUX: vol = h->vol_a; break;
+        case ADC_BUF_DISP_LEFT_WTA: src = h->snap_wta_l; debug_only = true; break;
+        case ADC_BUF_DISP_RIGHT_WTA: src = h->disp_r; break;
+        case ADC_BUF_DISP_OUTLIER: src = h->snap_outlier; debug_only = true; break;
+        case ADC_BUF_MASK_OCC: src = h->snap_occ; debug_only = true; break;
+        case ADC_BUF_MASK_MIS: src = h->snap_mis; debug_only = true; break;
+        case ADC_BUF_DISP_VOTING: src = h->snap_voting; debug_only = true; break;
+        case ADC_BUF_MASK_OCC_VOTING: src = h->occ; break;
+        case ADC_BUF_MASK_MIS_VOTING: src = h->mis; break;
+        case ADC_BUF_DISP_INTERP: src = h->snap_interp; debug_only = true; break;
+        case ADC_BUF_EDGE_MASK: src = h->edge; break;
+        case ADC_BUF_DISP_EDGE: src = h->cur_disp; break;
+        case ADC_BUF_DISP_FINAL: src = h->disp_final; break;
+        default: break;
+    }
+    if (debug_only && !h->snap_init)
+        return h->fail(ADC_ERR_ARG, "adc_get_buffer: this tap needs adc_set_debug_taps(h, 1) before the match");
+    if (vol) {
+        // internal volumes have row stride Dp >= D; hand out the reference's dense [H][W][D]
+        HIPCHK(h, hipMemcpy2D(dst, (size_t)h->g.D * 4, vol, (size_t)h->g.Dp * 4, (size_t)h->g.D * 4, npx,
+                              hipMemcpyDeviceToHost));
+        return ADC_OK;
+    }
+    if (!src) return h->fail(ADC_ERR_ARG, "adc_get_buffer: unknown buffer id");
+    HIPCHK(h, hipMemcpy(dst, src, need, hipMemcpyDeviceToHost));
+    return ADC_OK;
+}
+
+int adc_match_batch(const adc_batch_desc *d) {
+    if (!d || d->n_pairs < 0 || d->n_devices <= 0 || !d->devices || (d->n_pairs > 0 && (!d->left_bgr || !d->right_bgr || !d->disp_left))) {
+        g_thread_error = "adc_match_batch: bad descriptor";
+        return ADC_ERR_ARG;
+    }
+    const int nd = d->n_devices;
+    std::vector<int> rcs(nd, ADC_OK);
+    std::vector<std::string> errs(nd);
+    std::vector<std::thread> threads;
+    for (int di = 0; di < nd; di++) {
+        threads.emplace_back([&, di]() {
+            adc_handle *h = adc_create(d->devices[di]);
+            if (!h) { rcs[di] = ADC_ERR_NOMEM; errs[di] = "adc_create failed"; return; }
+            int rc = adc_initialize(h, d->width, d->height, &d->option);
+            for (int i = di; rc == ADC_OK && i < d->n_pairs; i += nd)
+                rc = adc_match(h, d->left_bgr[i], d->right_bgr[i], d->disp_left[i]);
+            if (rc != ADC_OK) { rcs[di] = rc; errs[di] = h->err; }
+            adc_destroy(h);
+        });
+    }
+    for (auto &t : threads) t.join();
+    for (int di = 0; di < nd; di++)
+        if (rcs[di] != ADC_OK) {
+            g_thread_error = "device " + std::to_string(d->devices[di]) + ": " + errs[di];
+            return rcs[di];
+        }
+    return ADC_OK;
+}
+
+const char *adc_last_error(adc_handle *h) {
+    if (!h) return g_thread_error.c_str();
+    return h->err.c_str();
+}
+
+}  // extern "C"

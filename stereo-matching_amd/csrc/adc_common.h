@@ -1,0 +1,88 @@
+// Internal declarations shared by the HIP translation units of libadcensus_hip.so.
+// gfx950 only: wave = 64 lanes everywhere.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define ADC_LARGE_F 99999.0f  // Large_Float of the reference (adcensus_types.h:54)
+#define ADC_WAVE 64
+
+namespace adc {
+
+// Frame geometry handed to every launcher. Volumes are f32[H][W][Dp] with Dp >= D the internal
+// disparity stride (D rounded up so each lane's disparity group is whole); entries k >= D are padding.
+struct Geom {
+    int W, H;
+    int dmin, dmax;
+    int D;   // dmax - dmin
+    int Dp;  // internal stride of the disparity axis
+    int NV;  // disparities per lane in the wave-per-pixel kernels: 64*NV >= D
+};
+
+// Per-pixel 2-D planes living in HBM for one handle.
+struct Planes {
+    const uint8_t *bgr_l, *bgr_r;   // caller images, u8[H][W][3]
+    uint32_t *pix_l, *pix_r;        // packed b | g<<8 | r<<16
+    uint8_t *gray_l, *gray_r;
+    uint32_t *cen_l, *cen_r;        // 31-bit centre-symmetric census
+    uint8_t *step_l, *step_r;       // colour-step flags: bit0 = vs left neighbour, bit1 = vs upper neighbour
+    uint32_t *arms;                 // left | right<<8 | top<<16 | bottom<<24
+    uint16_t *cnt_h, *cnt_v;
+};
+
+// --- adc_pre.hip -------------------------------------------------------------------------------
+void launch_pack_gray(const uint8_t *bgr, uint32_t *pix, uint8_t *gray, int W, int H, hipStream_t s);
+void launch_census(const uint8_t *gray, uint32_t *census, int W, int H, hipStream_t s);
+void launch_step_flags(const uint32_t *pix, uint8_t *flags, int W, int H, int tso, hipStream_t s);
+void launch_arms(const uint32_t *pix, uint32_t *arms, int W, int H, int L1, int L2, int t1, int t2, hipStream_t s);
+void launch_sup_counts(const uint32_t *arms, uint16_t *cnt_h, uint16_t *cnt_v, int W, int H, hipStream_t s);
+void launch_cost_init(const Planes &p, const Geom &g, const float *lut_ad, const float *lut_cen,
+                      float *cost, hipStream_t s);
+void launch_census_to_u64(const uint32_t *c32, uint64_t *c64, size_t n, hipStream_t s);
+
+// --- adc_aggregate.hip -------------------------------------------------------------------------
+// One directional pass: dst[p][k] = sum over the arm span of src (optionally / cnt[p]).
+// vertical = 0: span along x (left/right arms); 1: along y (top/bottom arms). cnt == nullptr: no division.
+// variant: 0 = ring kernel (LDS), 1 = direct-global fallback.
+void launch_aggregate_pass(const float *src, float *dst, const uint32_t *arms, const uint16_t *cnt,
+                           const Geom &g, int vertical, int max_arm, int variant, hipStream_t s);
+
+// --- adc_scanline.hip --------------------------------------------------------------------------
+// One directional scanline pass (src -> dst). Ptab = {P1[0..2], P2[0..2]} indexed by how many of
+// (d1,d2) reach tso.
+struct ScanParams { float P1[3]; float P2[3]; };
+void launch_scanline_pass(const float *src, float *dst, const Planes &p, const Geom &g,
+                          const ScanParams &sp, int vertical, int forward, hipStream_t s);
+
+// --- adc_wta.hip -------------------------------------------------------------------------------
+void launch_wta(const float *cost, float *disp_l, float *disp_r, const Geom &g, hipStream_t s);
+
+// --- adc_refine.hip ----------------------------------------------------------------------------
+struct RefineBufs {
+    float *disp_a, *disp_b;     // ping-pong disparity maps
+    const float *disp_r;
+    uint8_t *occ, *mis, *edge;
+    uint32_t *list_mis, *list_occ;   // compacted outlier pixel lists
+    uint32_t *counters;              // [0] = #mis, [1] = #occ
+    float *newval;                   // one pending value per list entry (mis list first, then occ)
+    const double *ray_dy, *ray_dx;   // [16][maxlen] products m*sin, m*cos
+};
+void launch_outlier(const float *dl, const float *dr, float *out, uint8_t *occ, uint8_t *mis,
+                    uint32_t *list_mis, uint32_t *list_occ, uint32_t *counters,
+                    int W, int H, float thres, hipStream_t s);
+void launch_clear_masks(uint8_t *occ, uint8_t *mis, uint32_t *counters, size_t n, hipStream_t s);
+void launch_region_voting_pass(float *disp, uint8_t *mask, const uint32_t *list, const uint32_t *count,
+                               float *newval, const uint32_t *arms, const Geom &g, int tau_s, float tau_h,
+                               hipStream_t s);
+void launch_interpolate(float *disp, const uint8_t *occ, const uint8_t *mis,
+                        const uint32_t *list_mis, const uint32_t *list_occ, const uint32_t *counters,
+                        float *newval, const uint32_t *pix_l, const double *ray_dy, const double *ray_dx,
+                        const Geom &g, int maxlen, hipStream_t s);
+void launch_edge_detect(const float *disp, uint8_t *edge, int W, int H, float thres, hipStream_t s);
+void launch_edge_adjust(const float *disp_in, float *disp_out, const float *cost, const uint8_t *edge,
+                        const Geom &g, hipStream_t s);
+void launch_median3(const float *in, float *out, int W, int H, hipStream_t s);
+
+}  // namespace adc

@@ -1,0 +1,243 @@
+// Per-pixel front end of the AD-Census path on gfx950: BGR packing + gray, 9x7 centre-symmetric
+// census, colour-step flags, cross arms, support counts and the initial AD-Census cost volume.
+// Reference: ADC/ = final_version_project/Stereo_Matching/ADCensus_CUDA/.
+#include "adc_common.h"
+
+namespace adc {
+
+__device__ __forceinline__ int color_dist(uint32_t p, uint32_t q) {
+    // max over the three channels of |p - q| (ColorDist, ADC/cross_aggregator.h:73-75)
+    const int d0 = abs((int)(p & 0xff) - (int)(q & 0xff));
+    const int d1 = abs((int)((p >> 8) & 0xff) - (int)((q >> 8) & 0xff));
+    const int d2 = abs((int)((p >> 16) & 0xff) - (int)((q >> 16) & 0xff));
+    return max(d0, max(d1, d2));
+}
+
+// ---- pack + gray ------------------------------------------------------------------------------
+// ComputeGrayCuda (ADC/cost_computor.cu:74-89): gray = uint8(r*0.299 + g*0.587 + b*0.114) in double,
+// left to right, no contraction (the library is built with -ffp-contract=off).
+__global__ void __launch_bounds__(256) k_pack_gray(const uint8_t *__restrict__ bgr, uint32_t *__restrict__ pix,
+                                                   uint8_t *__restrict__ gray, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = bgr[3 * i], g = bgr[3 * i + 1], r = bgr[3 * i + 2];
+    pix[i] = b | (g << 8) | (r << 16);
+    const double v = ((double)r * 0.299 + (double)g * 0.587) + (double)b * 0.114;
+    gray[i] = (uint8_t)(uint32_t)v;
+}
+
+void launch_pack_gray(const uint8_t *bgr, uint32_t *pix, uint8_t *gray, int W, int H, hipStream_t s) {
+    const size_t n = (size_t)W * H;
+    k_pack_gray<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(bgr, pix, gray, n);
+}
+
+// ---- census -----------------------------------------------------------------------------------
+// CenterSymmetricCensusKernelSM2 (ADC/census_cost.cu:9-98): 9x7 window, pixels outside the image
+// read as 0, 27 bits from the three upper rows against their point-mirrored partners plus 4 bits
+// from the left half of the centre row. One 64x16 output tile per 256-thread workgroup, the
+// (64+8)x(16+6) gray tile staged in LDS.
+#define CEN_TW 64
+#define CEN_TH 16
+#define CEN_LW (CEN_TW + 8)
+#define CEN_LH (CEN_TH + 6)
+__global__ void __launch_bounds__(256) k_census(const uint8_t *__restrict__ gray, uint32_t *__restrict__ census,
+                                                int W, int H) {
+    __shared__ uint8_t tile[CEN_LH][CEN_LW];
+    const int x0 = blockIdx.x * CEN_TW, y0 = blockIdx.y * CEN_TH;
+    for (int i = threadIdx.x; i < CEN_LH * CEN_LW; i += 256) {
+        const int ly = i / CEN_LW, lx = i - ly * CEN_LW;
+        const int gy = y0 + ly - 3, gx = x0 + lx - 4;
+        tile[ly][lx] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? gray[(size_t)gy * W + gx] : (uint8_t)0;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int ly = ty + 4 * r;           // tile row of the output pixel
+        const int x = x0 + tx, y = y0 + ly;
+        if (x >= W || y >= H) continue;
+        uint32_t c = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+#pragma unroll
+            for (int m = 0; m < 9; m++) {
+                const uint8_t e1 = tile[ly + k][tx + m];
+                const uint8_t e2 = tile[ly + 6 - k][tx + 8 - m];
+                c |= (uint32_t)(e1 >= e2) << (k * 9 + m);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const uint8_t e1 = tile[ly + 3][tx + m];
+            const uint8_t e2 = tile[ly + 3][tx + 8 - m];
+            c |= (uint32_t)(e1 >= e2) << (27 + m);
+        }
+        census[(size_t)y * W + x] = c;
+    }
+}
+
+void launch_census(const uint8_t *gray, uint32_t *census, int W, int H, hipStream_t s) {
+    dim3 grid((W + CEN_TW - 1) / CEN_TW, (H + CEN_TH - 1) / CEN_TH);
+    k_census<<<grid, dim3(256), 0, s>>>(gray, census, W, H);
+}
+
+__global__ void __launch_bounds__(256) k_census_to_u64(const uint32_t *__restrict__ c32, uint64_t *__restrict__ c64, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) c64[i] = (uint64_t)c32[i];
+}
+void launch_census_to_u64(const uint32_t *c32, uint64_t *c64, size_t n, hipStream_t s) {
+    k_census_to_u64<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(c32, c64, n);
+}
+
+// ---- colour-step flags ------------------------------------------------------------------------
+// The scanline recurrence compares the max-channel colour distance between consecutive path pixels
+// with so_tso (ADC/scanline_optimizer.cu:73-74,90-91,98-109). Both directions of a path see the same
+// pixel pair, so one flag per pixel pair is enough: bit0 = dist(p[y][x], p[y][x-1]) >= tso,
+// bit1 = dist(p[y][x], p[y-1][x]) >= tso.
+__global__ void __launch_bounds__(256) k_step_flags(const uint32_t *__restrict__ pix, uint8_t *__restrict__ flags,
+                                                    int W, int H, int tso) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const size_t i = (size_t)y * W + x;
+    const uint32_t p = pix[i];
+    uint8_t f = 0;
+    if (x >= 1 && color_dist(p, pix[i - 1]) >= tso) f |= 1;
+    if (y >= 1 && color_dist(p, pix[i - W]) >= tso) f |= 2;
+    flags[i] = f;
+}
+void launch_step_flags(const uint32_t *pix, uint8_t *flags, int W, int H, int tso, hipStream_t s) {
+    dim3 grid((W + 63) / 64, (H + 3) / 4);
+    k_step_flags<<<grid, dim3(256), 0, s>>>(pix, flags, W, H, tso);
+}
+
+// ---- cross arms -------------------------------------------------------------------------------
+// FindHorizontalArm / FindVerticalArm (ADC/cost_aggregator.cu:130-260) on the left image.
+__device__ __forceinline__ uint32_t find_arm(const uint32_t *__restrict__ pix, int W, int H, int x, int y,
+                                             int dx, int dy, uint32_t p0, int cap, int L2, int t1, int t2) {
+    uint32_t last = p0;
+    int xn = x + dx, yn = y + dy;
+    uint32_t arm = 0;
+    for (int n = 0; n < cap; n++) {
+        if (xn < 0 || xn >= W || yn < 0 || yn >= H) break;
+        const uint32_t p = pix[(size_t)yn * W + xn];
+        const int d1 = color_dist(p, p0);
+        if (d1 >= t1) break;
+        if (n > 0 && color_dist(p, last) >= t1) break;
+        if (n + 1 > L2 && d1 >= t2) break;
+        arm++;
+        last = p;
+        xn += dx;
+        yn += dy;
+    }
+    return arm;
+}
+
+__global__ void __launch_bounds__(256) k_arms(const uint32_t *__restrict__ pix, uint32_t *__restrict__ arms,
+                                              int W, int H, int cap, int L2, int t1, int t2) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const uint32_t p0 = pix[(size_t)y * W + x];
+    const uint32_t l = find_arm(pix, W, H, x, y, -1, 0, p0, cap, L2, t1, t2);
+    const uint32_t r = find_arm(pix, W, H, x, y, +1, 0, p0, cap, L2, t1, t2);
+    const uint32_t t = find_arm(pix, W, H, x, y, 0, -1, p0, cap, L2, t1, t2);
+    const uint32_t b = find_arm(pix, W, H, x, y, 0, +1, p0, cap, L2, t1, t2);
+    arms[(size_t)y * W + x] = l | (r << 8) | (t << 16) | (b << 24);
+}
+void launch_arms(const uint32_t *pix, uint32_t *arms, int W, int H, int L1, int L2, int t1, int t2, hipStream_t s) {
+    const int cap = L1 < 255 ? L1 : 255;  // min(cross_L1, MAX_ARM_LENGTH), ADC/cost_aggregator.cu:145
+    dim3 grid((W + 63) / 64, (H + 3) / 4);
+    k_arms<<<grid, dim3(256), 0, s>>>(pix, arms, W, H, cap, L2, t1, t2);
+}
+
+// ---- support pixel counts -----------------------------------------------------------------------
+// ComputeSupPixelCount (ADC/cost_aggregator.cu:262-316).
+__global__ void __launch_bounds__(256) k_sup_counts(const uint32_t *__restrict__ arms, uint16_t *__restrict__ cnt_h,
+                                                    uint16_t *__restrict__ cnt_v, int W, int H) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const size_t i = (size_t)y * W + x;
+    const uint32_t a = arms[i];
+    const int l = a & 0xff, r = (a >> 8) & 0xff, t = (a >> 16) & 0xff, b = a >> 24;
+    int ch = 0, cv = 0;
+    for (int dy = -t; dy <= b; dy++) {
+        const uint32_t q = arms[i + (ptrdiff_t)dy * W];
+        ch += (int)(q & 0xff) + (int)((q >> 8) & 0xff) + 1;
+    }
+    for (int dx = -l; dx <= r; dx++) {
+        const uint32_t q = arms[i + dx];
+        cv += (int)((q >> 16) & 0xff) + (int)(q >> 24) + 1;
+    }
+    cnt_h[i] = (uint16_t)ch;
+    cnt_v[i] = (uint16_t)cv;
+}
+void launch_sup_counts(const uint32_t *arms, uint16_t *cnt_h, uint16_t *cnt_v, int W, int H, hipStream_t s) {
+    dim3 grid((W + 63) / 64, (H + 3) / 4);
+    k_sup_counts<<<grid, dim3(256), 0, s>>>(arms, cnt_h, cnt_v, W, H);
+}
+
+// ---- initial cost volume ------------------------------------------------------------------------
+// ComputeCostCuda (ADC/cost_computor.cu:151-207) with the runtime disparity range:
+//   cost = ((1 - e_ad[sum|dBGR|]) + 1) - e_cen[popcount(cenL ^ cenR)], 1.0f when x-d is outside the image.
+// e_ad / e_cen are the host-built tables of expf(-ad/lambda_ad) and expf(-h/lambda_census).
+// One workgroup = one row segment of 64 pixels; the right-image entries {packed BGR, census} that
+// any of its (pixel, disparity) pairs can touch are staged once in LDS; lane <-> disparity so every
+// store instruction writes 256 contiguous bytes of the [H][W][Dp] volume.
+#define COST_TX 64
+__global__ void __launch_bounds__(256) k_cost_init(const uint32_t *__restrict__ pix_l, const uint32_t *__restrict__ pix_r,
+                                                   const uint32_t *__restrict__ cen_l, const uint32_t *__restrict__ cen_r,
+                                                   const float *__restrict__ lut_ad, const float *__restrict__ lut_cen,
+                                                   float *__restrict__ cost, int W, int H, int dmin, int D, int Dp) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    float *s_ad = reinterpret_cast<float *>(smem);        // 766 (+2 pad)
+    float *s_cen = s_ad + 768;                            // 65 (+3 pad)
+    uint2 *s_r = reinterpret_cast<uint2 *>(s_cen + 68);   // COST_TX + D entries
+    const int y = blockIdx.y;
+    const int x0 = blockIdx.x * COST_TX;
+    const int dmax = dmin + D;
+    const int base = x0 - dmax + 1;           // smallest right column any pair of this segment touches
+    const int nr = COST_TX + D - 1;
+    for (int i = threadIdx.x; i < 766; i += 256) s_ad[i] = lut_ad[i];
+    if (threadIdx.x < 65) s_cen[threadIdx.x] = lut_cen[threadIdx.x];
+    for (int i = threadIdx.x; i < nr; i += 256) {
+        const int xr = base + i;
+        uint2 v = make_uint2(0u, 0u);
+        if (xr >= 0 && xr < W) {
+            const size_t q = (size_t)y * W + xr;
+            v = make_uint2(pix_r[q], cen_r[q]);
+        }
+        s_r[i] = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int xi = wave; xi < COST_TX; xi += 4) {
+        const int x = x0 + xi;
+        if (x >= W) break;
+        const size_t p = (size_t)y * W + x;
+        const uint32_t pl = pix_l[p], cl = cen_l[p];
+        float *out = cost + p * (size_t)Dp;
+        for (int k = lane; k < D; k += 64) {
+            const int xr = x - dmin - k;
+            float c = 1.0f;
+            if (xr >= 0 && xr < W) {
+                const uint2 r = s_r[xr - base];
+                const uint32_t sad = __builtin_amdgcn_sad_u8(pl, r.x, 0u);
+                const uint32_t ham = __builtin_popcount(cl ^ r.y);
+                c = ((1.0f - s_ad[sad]) + 1.0f) - s_cen[ham];
+            }
+            out[k] = c;
+        }
+    }
+}
+
+void launch_cost_init(const Planes &p, const Geom &g, const float *lut_ad, const float *lut_cen,
+                      float *cost, hipStream_t s) {
+    dim3 grid((g.W + COST_TX - 1) / COST_TX, g.H);
+    const size_t lds = (768 + 68) * sizeof(float) + (size_t)(COST_TX + g.D) * sizeof(uint2);
+    k_cost_init<<<grid, dim3(256), lds, s>>>(p.pix_l, p.pix_r, p.cen_l, p.cen_r, lut_ad, lut_cen, cost,
+                                            g.W, g.H, g.dmin, g.D, g.Dp);
+}
+
+}  // namespace adc

@@ -1,0 +1,311 @@
+// Multi-step disparity refinement on gfx950 (MultiStepRefiner, ADC/multistep_refiner.cu;
+// ADC/ = final_version_project/Stereo_Matching/ADCensus_CUDA/): left-right outlier detection,
+// iterative region voting, 16-direction interpolation, sobel edges + discontinuity adjustment and
+// the 3x3 median. Every step reads the disparity map as it was when the step started and writes its
+// results afterwards (the reference updates the map in place while other threads read it).
+//
+// Outlier pixels are compacted into two lists (mismatch / occlusion) when they are detected; the
+// voting and interpolation steps then run over the lists only instead of over the whole image.
+#include "adc_common.h"
+
+namespace adc {
+
+#define ADC_INF __int_as_float(0x7f800000)
+
+// lround() of the reference: round half away from zero.
+__device__ __forceinline__ int lround_f(float v) { return (int)roundf(v); }
+
+// ---- outlier detection (OutlierDetectionCuda, ADC/multistep_refiner.cu:70-156) --------------------
+__global__ void __launch_bounds__(256)
+k_outlier(const float *__restrict__ dl, const float *__restrict__ dr, float *__restrict__ out,
+          uint8_t *__restrict__ occ, uint8_t *__restrict__ mis, uint32_t *__restrict__ list_mis,
+          uint32_t *__restrict__ list_occ, uint32_t *__restrict__ counters, int W, int H, float thres) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const size_t i = (size_t)y * W + x;
+    const float d = dl[i];
+    float o = d;
+    bool is_occ = false, is_mis = false;
+    if (d < 0) {                      // MinDispMismatch = 0 (ADC/config.h:4)
+        o = ADC_INF; is_mis = true;
+    } else if (d == ADC_INF) {
+        is_mis = true;
+    } else {
+        const int cr = lround_f((float)x - d);
+        if (cr >= 0 && cr < W) {
+            const float r = dr[(size_t)y * W + cr];
+            if (fabsf(d - r) > thres) {
+                const int crl = lround_f((float)cr + r);
+                if (crl > 0 && crl < W) {
+                    const float l2 = dl[(size_t)y * W + crl];
+                    if (l2 > d) is_occ = true; else is_mis = true;
+                } else {
+                    is_mis = true;
+                }
+                o = ADC_INF;
+            }
+        } else {
+            o = ADC_INF; is_mis = true;
+        }
+    }
+    out[i] = o;
+    occ[i] = is_occ;
+    mis[i] = is_mis;
+    if (is_mis) list_mis[atomicAdd(&counters[0], 1u)] = (uint32_t)i;
+    if (is_occ) list_occ[atomicAdd(&counters[1], 1u)] = (uint32_t)i;
+}
+
+void launch_outlier(const float *dl, const float *dr, float *out, uint8_t *occ, uint8_t *mis,
+                    uint32_t *list_mis, uint32_t *list_occ, uint32_t *counters,
+                    int W, int H, float thres, hipStream_t s) {
+    hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), s);
+    dim3 grid((W + 63) / 64, (H + 3) / 4);
+    k_outlier<<<grid, dim3(256), 0, s>>>(dl, dr, out, occ, mis, list_mis, list_occ, counters, W, H, thres);
+}
+
+void launch_clear_masks(uint8_t *occ, uint8_t *mis, uint32_t *counters, size_t n, hipStream_t s) {
+    hipMemsetAsync(occ, 0, n, s);
+    hipMemsetAsync(mis, 0, n, s);
+    hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), s);
+}
+
+// ---- iterative region voting (RegionVotingCuda + DeleteFilledPixel, ADC/multistep_refiner.cu:376-449)
+// One wavefront (= one 64-thread workgroup slot) per listed pixel: the disparity histogram of the
+// cross support region is built in LDS, lanes striding over each row's horizontal span.
+__global__ void __launch_bounds__(64)
+k_vote(const float *__restrict__ disp, const uint8_t *__restrict__ mask, const uint32_t *__restrict__ list,
+       const uint32_t *__restrict__ count, float *__restrict__ newval, const uint32_t *__restrict__ arms,
+       int W, int dmin, int D, int tau_s, float tau_h) {
+    extern __shared__ int hist[];
+    const int lane = threadIdx.x;
+    const uint32_t n = *count;
+    for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
+        const uint32_t p = list[e];
+        float result = ADC_INF;
+        if (mask[p] && disp[p] == ADC_INF) {   // uniform across the wave
+            for (int k = lane; k < D; k += 64) hist[k] = 0;
+            __syncthreads();
+            const uint32_t a = arms[p];
+            const int top = (a >> 16) & 0xff, bot = a >> 24;
+            for (int t = -top; t <= bot; t++) {
+                const size_t q = (size_t)p + (ptrdiff_t)t * W;
+                const uint32_t a2 = arms[q];
+                const int l2 = a2 & 0xff, r2 = (a2 >> 8) & 0xff;
+                for (int s = lane - l2; s <= r2; s += 64) {
+                    const float dd = disp[q + s];
+                    if (dd != ADC_INF) {
+                        const int bin = lround_f(dd) - dmin;
+                        if (bin >= 0 && bin < D) atomicAdd(&hist[bin], 1);
+                    }
+                }
+            }
+            __syncthreads();
+            // first bin holding the maximum count, and the total
+            int mh = 0, mk = 0x7fffffff, cnt = 0;
+            for (int k = lane; k < D; k += 64) {
+                const int h = hist[k];
+                if (mh < h) { mh = h; mk = k; }
+                cnt += h;
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const int oh = __shfl_xor(mh, off, 64);
+                const int ok = __shfl_xor(mk, off, 64);
+                cnt += __shfl_xor(cnt, off, 64);
+                if (oh > mh || (oh == mh && ok < mk)) { mh = oh; mk = ok; }
+            }
+            if (mh > 0) {
+                if (cnt > tau_s && mh * 1.0f / cnt > tau_h) result = mk + (float)dmin;
+            }
+            __syncthreads();
+        }
+        if (lane == 0) newval[e] = result;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_apply(float *__restrict__ disp, uint8_t *__restrict__ mask, const uint32_t *__restrict__ list,
+        const uint32_t *__restrict__ count, const float *__restrict__ newval) {
+    const uint32_t n = *count;
+    for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+        const float v = newval[e];
+        if (v != ADC_INF) {
+            const uint32_t p = list[e];
+            disp[p] = v;
+            mask[p] = 0;
+        }
+    }
+}
+
+void launch_region_voting_pass(float *disp, uint8_t *mask, const uint32_t *list, const uint32_t *count,
+                               float *newval, const uint32_t *arms, const Geom &g, int tau_s, float tau_h,
+                               hipStream_t s) {
+    k_vote<<<dim3(8192), dim3(64), (size_t)g.D * sizeof(int), s>>>(disp, mask, list, count, newval, arms,
+                                                                  g.W, g.dmin, g.D, tau_s, tau_h);
+    k_apply<<<dim3(512), dim3(256), 0, s>>>(disp, mask, list, count, newval);
+}
+
+// ---- proper interpolation (FillDisp, ADC/multistep_refiner.cu:543-633) ------------------------------
+// ray_dy / ray_dx hold the host-computed products m*sin(ang_s), m*cos(ang_s) (double) for the 16
+// directions, so the device only adds and rounds.
+__global__ void __launch_bounds__(256)
+k_interp(const float *__restrict__ disp, const uint8_t *__restrict__ occ, const uint8_t *__restrict__ mis,
+         const uint32_t *__restrict__ list_mis, const uint32_t *__restrict__ list_occ,
+         const uint32_t *__restrict__ counters, float *__restrict__ newval, const uint32_t *__restrict__ pix,
+         const double *__restrict__ ray_dy, const double *__restrict__ ray_dx, int W, int H, int maxlen,
+         size_t npx) {
+    const uint32_t n_mis = counters[0], n_occ = counters[1];
+    const uint32_t n = n_mis + n_occ;
+    for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+        const bool from_mis = e < n_mis;
+        const uint32_t p = from_mis ? list_mis[e] : list_occ[e - n_mis];
+        const size_t slot = from_mis ? (size_t)e : npx + (e - n_mis);
+        float result = ADC_INF;
+        const bool m = mis[p] != 0, o = occ[p] != 0;
+        if (m || o) {
+            const int y = (int)(p / (uint32_t)W), x = (int)(p - (uint32_t)y * W);
+            const uint32_t c0 = pix[p];
+            int best_diff = 9999;
+            float best_d = 0.0f, min_d = ADC_LARGE_F;
+            int num = 0;
+            for (int s = 0; s < 16; s++) {
+                const double *dy = ray_dy + (size_t)s * maxlen;
+                const double *dx = ray_dx + (size_t)s * maxlen;
+                for (int mm = 1; mm < maxlen; mm++) {
+                    const int yy = (int)round((double)y + dy[mm]);
+                    const int xx = (int)round((double)x + dx[mm]);
+                    if (yy < 0 || yy >= H || xx < 0 || xx >= W) break;
+                    const size_t q = (size_t)yy * W + xx;
+                    const float d = disp[q];
+                    if (d != ADC_INF) {
+                        num++;
+                        const int diff = (int)__builtin_amdgcn_sad_u8(c0, pix[q], 0u);
+                        if (best_diff > diff) { best_diff = diff; best_d = d; }
+                        min_d = d < min_d ? d : min_d;
+                        break;
+                    }
+                }
+            }
+            if (num) result = m ? best_d : min_d;
+        }
+        newval[slot] = result;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_apply_interp(float *__restrict__ disp, const uint32_t *__restrict__ list_mis, const uint32_t *__restrict__ list_occ,
+               const uint32_t *__restrict__ counters, const float *__restrict__ newval, size_t npx) {
+    const uint32_t n_mis = counters[0], n_occ = counters[1];
+    const uint32_t n = n_mis + n_occ;
+    for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+        const bool from_mis = e < n_mis;
+        const uint32_t p = from_mis ? list_mis[e] : list_occ[e - n_mis];
+        const float v = newval[from_mis ? (size_t)e : npx + (e - n_mis)];
+        if (v != ADC_INF) disp[p] = v;
+    }
+}
+
+void launch_interpolate(float *disp, const uint8_t *occ, const uint8_t *mis,
+                        const uint32_t *list_mis, const uint32_t *list_occ, const uint32_t *counters,
+                        float *newval, const uint32_t *pix_l, const double *ray_dy, const double *ray_dx,
+                        const Geom &g, int maxlen, hipStream_t s) {
+    const size_t npx = (size_t)g.W * g.H;
+    k_interp<<<dim3(2048), dim3(256), 0, s>>>(disp, occ, mis, list_mis, list_occ, counters, newval, pix_l,
+                                             ray_dy, ray_dx, g.W, g.H, maxlen, npx);
+    k_apply_interp<<<dim3(512), dim3(256), 0, s>>>(disp, list_mis, list_occ, counters, newval, npx);
+}
+
+// ---- sobel edges (EdgeDetectCuda, ADC/multistep_refiner.cu:161-180) ---------------------------------
+__global__ void __launch_bounds__(256)
+k_edge_detect(const float *__restrict__ disp, uint8_t *__restrict__ edge, int W, int H, float thres) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    uint8_t e = 0;
+    if (y >= 1 && y < H - 1 && x >= 1 && x < W - 1) {
+        const float *r0 = disp + (size_t)(y - 1) * W + x;
+        const float *r1 = disp + (size_t)y * W + x;
+        const float *r2 = disp + (size_t)(y + 1) * W + x;
+        const float gx = (-r0[-1] + r0[1]) + (-2 * r1[-1] + 2 * r1[1]) + (-r2[-1] + r2[1]);
+        const float gy = (-r0[-1] - 2 * r0[0] - r0[1]) + (r2[-1] + 2 * r2[0] + r2[1]);
+        const float gsum = fabsf(gx) + fabsf(gy);
+        if (gsum > thres) e = 1;   // NaN (inf - inf) compares false
+    }
+    edge[(size_t)y * W + x] = e;
+}
+void launch_edge_detect(const float *disp, uint8_t *edge, int W, int H, float thres, hipStream_t s) {
+    dim3 grid((W + 63) / 64, (H + 3) / 4);
+    k_edge_detect<<<grid, dim3(256), 0, s>>>(disp, edge, W, H, thres);
+}
+
+// ---- discontinuity adjustment (EdgeDispOptmize, ADC/multistep_refiner.cu:685-751) -------------------
+__global__ void __launch_bounds__(256)
+k_edge_adjust(const float *__restrict__ din, float *__restrict__ dout, const float *__restrict__ cost,
+              const uint8_t *__restrict__ edge, int W, int H, int dmin, int D, int Dp) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const size_t i = (size_t)y * W + x;
+    float d = din[i];
+    if (x >= 1 && x < W - 1 && edge[i] == 1 && d != ADC_INF) {
+        const float *cp = cost + i * (size_t)Dp;
+        const int di = lround_f(d) - dmin;
+        if (di >= 0 && di < D) {
+            float c0 = cp[di];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const float d2 = din[k == 0 ? i - 1 : i + 1];
+                if (d2 != ADC_INF) {
+                    const int d2i = lround_f(d2) - dmin;
+                    if (d2i >= 0 && d2i < D) {
+                        const float c = (k == 0) ? cp[-(ptrdiff_t)Dp + d2i] : cp[Dp + d2i];
+                        if (c < c0) { d = d2; c0 = c; }
+                    }
+                }
+            }
+        }
+    }
+    dout[i] = d;
+}
+void launch_edge_adjust(const float *disp_in, float *disp_out, const float *cost, const uint8_t *edge,
+                        const Geom &g, hipStream_t s) {
+    dim3 grid((g.W + 63) / 64, (g.H + 3) / 4);
+    k_edge_adjust<<<grid, dim3(256), 0, s>>>(disp_in, disp_out, cost, edge, g.W, g.H, g.dmin, g.D, g.Dp);
+}
+
+// ---- 3x3 median (MedianFilter<3>, ADC/multistep_refiner.cu:186-224) ----------------------------------
+__global__ void __launch_bounds__(256)
+k_median3(const float *__restrict__ in, float *__restrict__ out, int W, int H) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const size_t i = (size_t)y * W + x;
+    if (y >= 1 && x >= 1 && y < H - 1 && x < W - 1) {
+        float w[9];
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) w[a * 3 + b] = in[(size_t)(y - 1 + a) * W + x - 1 + b];
+        // the reference's partial selection sort, as a fixed compare-exchange network over (a, b > a)
+#pragma unroll
+        for (int a = 0; a < 5; a++) {
+#pragma unroll
+            for (int b = a + 1; b < 9; b++) {
+                const float lo = w[b] < w[a] ? w[b] : w[a];
+                const float hi = w[b] < w[a] ? w[a] : w[b];
+                w[a] = lo;
+                w[b] = hi;
+            }
+        }
+        out[i] = w[4];
+    } else {
+        out[i] = in[i];
+    }
+}
+void launch_median3(const float *in, float *out, int W, int H, hipStream_t s) {
+    dim3 grid((W + 63) / 64, (H + 3) / 4);
+    k_median3<<<grid, dim3(256), 0, s>>>(in, out, W, H);
+}
+
+}  // namespace adc
