@@ -4,6 +4,8 @@ import sys
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  -- first, so the process holds ONE HIP runtime (torch's bundled libamdhip64.so.7);
+#                              libadcensus_hip.so then binds to it by soname and can share torch's streams/memory
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
