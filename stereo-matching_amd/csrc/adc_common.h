@@ -30,6 +30,7 @@ struct Planes {
     uint8_t *step_l, *step_r;       // colour-step flags: bit0 = vs left neighbour, bit1 = vs upper neighbour
     uint32_t *arms;                 // left | right<<8 | top<<16 | bottom<<24
     uint16_t *cnt_h, *cnt_v;
+    uint32_t *cnt_h32, *cnt_v32;    // same counts widened to 32 bits (dword scalar loads in the aggregation kernel)
 };
 
 // --- adc_pre.hip -------------------------------------------------------------------------------
@@ -37,7 +38,8 @@ void launch_pack_gray(const uint8_t *bgr, uint32_t *pix, uint8_t *gray, int W, i
 void launch_census(const uint8_t *gray, uint32_t *census, int W, int H, hipStream_t s);
 void launch_step_flags(const uint32_t *pix, uint8_t *flags, int W, int H, int tso, hipStream_t s);
 void launch_arms(const uint32_t *pix, uint32_t *arms, int W, int H, int L1, int L2, int t1, int t2, hipStream_t s);
-void launch_sup_counts(const uint32_t *arms, uint16_t *cnt_h, uint16_t *cnt_v, int W, int H, hipStream_t s);
+void launch_sup_counts(const uint32_t *arms, uint16_t *cnt_h, uint16_t *cnt_v, uint32_t *cnt_h32, uint32_t *cnt_v32,
+                       int W, int H, hipStream_t s);
 void launch_cost_init(const Planes &p, const Geom &g, const float *lut_ad, const float *lut_cen,
                       float *cost, hipStream_t s);
 void launch_census_to_u64(const uint32_t *c32, uint64_t *c64, size_t n, hipStream_t s);
@@ -46,7 +48,7 @@ void launch_census_to_u64(const uint32_t *c32, uint64_t *c64, size_t n, hipStrea
 // One directional pass: dst[p][k] = sum over the arm span of src (optionally / cnt[p]).
 // vertical = 0: span along x (left/right arms); 1: along y (top/bottom arms). cnt == nullptr: no division.
 // variant: 0 = ring kernel (LDS), 1 = direct-global fallback.
-void launch_aggregate_pass(const float *src, float *dst, const uint32_t *arms, const uint16_t *cnt,
+void launch_aggregate_pass(const float *src, float *dst, const uint32_t *arms, const uint32_t *cnt,
                            const Geom &g, int vertical, int max_arm, int variant, hipStream_t s);
 
 // --- adc_scanline.hip --------------------------------------------------------------------------

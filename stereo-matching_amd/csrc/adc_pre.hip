@@ -154,7 +154,8 @@ void launch_arms(const uint32_t *pix, uint32_t *arms, int W, int H, int L1, int 
 // ---- support pixel counts -----------------------------------------------------------------------
 // ComputeSupPixelCount (ADC/cost_aggregator.cu:262-316).
 __global__ void __launch_bounds__(256) k_sup_counts(const uint32_t *__restrict__ arms, uint16_t *__restrict__ cnt_h,
-                                                    uint16_t *__restrict__ cnt_v, int W, int H) {
+                                                    uint16_t *__restrict__ cnt_v, uint32_t *__restrict__ cnt_h32,
+                                                    uint32_t *__restrict__ cnt_v32, int W, int H) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
@@ -172,10 +173,13 @@ __global__ void __launch_bounds__(256) k_sup_counts(const uint32_t *__restrict__
     }
     cnt_h[i] = (uint16_t)ch;
     cnt_v[i] = (uint16_t)cv;
+    cnt_h32[i] = (uint32_t)(uint16_t)ch;
+    cnt_v32[i] = (uint32_t)(uint16_t)cv;
 }
-void launch_sup_counts(const uint32_t *arms, uint16_t *cnt_h, uint16_t *cnt_v, int W, int H, hipStream_t s) {
+void launch_sup_counts(const uint32_t *arms, uint16_t *cnt_h, uint16_t *cnt_v, uint32_t *cnt_h32, uint32_t *cnt_v32,
+                       int W, int H, hipStream_t s) {
     dim3 grid((W + 63) / 64, (H + 3) / 4);
-    k_sup_counts<<<grid, dim3(256), 0, s>>>(arms, cnt_h, cnt_v, W, H);
+    k_sup_counts<<<grid, dim3(256), 0, s>>>(arms, cnt_h, cnt_v, cnt_h32, cnt_v32, W, H);
 }
 
 // ---- initial cost volume ------------------------------------------------------------------------
@@ -211,7 +215,8 @@ __global__ void __launch_bounds__(256) k_cost_init(const uint32_t *__restrict__ 
         s_r[i] = v;
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int xi = wave; xi < COST_TX; xi += 4) {
         const int x = x0 + xi;
         if (x >= W) break;

@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(256)
 k_scanline(const float *__restrict__ src, float *__restrict__ dst, const uint8_t *__restrict__ step_l,
            const uint8_t *__restrict__ step_r, int W, int H, int dmin, int D, int Dp, int forward, ScanParams sp) {
     const int lane = threadIdx.x & 63;
-    const int line = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int line = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nlines = VERT ? W : H;
     if (line >= nlines) return;
     const int LEN = VERT ? H : W;

@@ -27,7 +27,7 @@ __device__ __forceinline__ float subpixel(float best, float c1, float c2, float 
 __global__ void __launch_bounds__(256)
 k_wta_left(const float *__restrict__ cost, float *__restrict__ disp, size_t npx, int dmin, int D, int Dp) {
     const int lane = threadIdx.x & 63;
-    const size_t p = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t p = (size_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (p >= npx) return;
     const float *c = cost + p * (size_t)Dp;
     float mv = ADC_LARGE_F;
@@ -57,7 +57,7 @@ k_wta_left(const float *__restrict__ cost, float *__restrict__ disp, size_t npx,
 __global__ void __launch_bounds__(256)
 k_wta_right(const float *__restrict__ cost, float *__restrict__ disp, int W, int H, int dmin, int D, int Dp) {
     const int lane = threadIdx.x & 63;
-    const size_t p = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t p = (size_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (p >= (size_t)W * H) return;
     const int y = (int)(p / W), xr = (int)(p - (size_t)y * W);
     const float *row = cost + (size_t)y * W * Dp;
