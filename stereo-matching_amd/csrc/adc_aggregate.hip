@@ -8,215 +8,164 @@
 // between pass 1 and pass 2 that the reference's single launch lacks.
 //
 // Lanes run along the disparity axis: the arms of a pixel are the same for all of its disparities,
-// so the span bounds are wave-uniform scalars, every global access of a wave is 256 contiguous
-// bytes, and each lane adds its span in ascending t starting from 0.0f -- the reference's order
+// so the span bounds are wave-uniform scalars, every global access of a wave is contiguous, and each
+// lane adds its span in ascending t starting from 0.0f -- the reference's order
 // (ADC/cost_aggregator.cu:346-372), so the sums are bit-identical to a sequential CPU evaluation.
 //
-// Ring kernel: a 256-thread workgroup owns one scanline (a row for horizontal passes, a column for
-// vertical ones) x 64 disparities and marches along it. The last 2*cap+1 (+2 blocks) input
-// positions live in an LDS ring [R][64] floats, so each input element is fetched from HBM exactly
-// once per pass and re-read up to 2*cap+1 times from LDS (conflict-free: lane <-> bank).
+// Ring kernel: a 512-thread workgroup (8 waves) owns one scanline (a row for horizontal passes, a
+// column for vertical ones) x 64*VEC disparities and marches along it, 8 output positions per
+// iteration (one per wave). The input positions any in-flight block can touch live in an LDS ring
+// [R][64*VEC] floats, so each input element is fetched from HBM once per pass and re-read up to
+// 2*cap+1 times from LDS (lane l reads floats l*VEC.. of a slot: conflict-free ds_read_b32/b64).
 #include "adc_common.h"
+
+#include <cstdlib>
 
 namespace adc {
 
-#define AGG_B 16   // output positions per workgroup iteration
-#define AGG_JB 4   // consecutive output positions one wave produces together
+#define AGG_WAVES 16   // waves per workgroup = output positions per iteration
 
-// Ring fill: one LDS-DMA per (march position, wave): 64 lanes x 4 B land at ring[slot][0..63] with no
-// VGPR or ds_write in between. The destination is wave-uniform (slot base); the hardware adds lane*4.
-__device__ __forceinline__ void ring_fill(const float *gsrc, float *ring_slot) {
-    __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void *)ring_slot, 4, 0, 0);
+template <int VEC> struct VecT;
+template <> struct VecT<1> { typedef float T; };
+template <> struct VecT<2> { typedef float T __attribute__((ext_vector_type(2))); };
+
+// Ring fill: one LDS-DMA per 64 consecutive floats of a slot: 64 lanes x 4 B land at dst[0..63] with
+// no VGPR or ds_write in between. The destination is wave-uniform; the hardware adds lane*4.
+__device__ __forceinline__ void ring_fill(const float *gsrc, float *lds_dst) {
+    __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void *)lds_dst, 4, 0, 0);
 }
 
-// One ring value feeds up to AGG_JB accumulators: consecutive outputs have heavily overlapping
-// spans, so each LDS read is shared by the JB sums whose span contains that position. Over the
-// positions common to all JB spans the adds are unconditional; over the ragged head and tail a
-// position is added as (inside span j ? v : 0.0f), and adding +0.0f to a non-negative sum is the
-// identity, so this is bit-identical to "add" / "skip". Every accumulator still receives exactly
-// its own span in ascending order, starting from 0.0f.
-//
-// Pipeline per workgroup iteration i (block of AGG_B outputs starting at o0):
-//   issue the fills of block i+2's new input positions -> compute + store block i ->
+// One ring read = one ds_read_b32 / ds_read_b64. The access is volatile so that the compiler does not
+// pair two of them into ds_read2(st64)_b64: on gfx950 the paired form runs at half the LDS rate
+// (8 cycles per wave-instruction against 2 for a single ds_read_b64).
+template <typename T>
+__device__ __forceinline__ T ring_read(const float *p) {
+    typedef const volatile T __attribute__((address_space(3))) *lds_ptr;
+    return *(lds_ptr)(uintptr_t)p;   // generic LDS address: its low 32 bits are the LDS offset
+}
+
+// Pipeline per workgroup iteration i (outputs o0 .. o0+7, wave w produces o0+w):
+//   issue the fills of the positions block i+DEPTH adds to the window -> compute + store block i ->
 //   wait until block i+1's fills have landed (counted vmcnt) -> barrier.
-// Fills and stores retire in issue order on one counter. At the wait of iteration i a wave's newest
-// operations are: 4 stores of block i-1, 4 fills issued in iteration i, 4 stores of block i -- so
-// vmcnt(12) returns exactly when the 4 fills issued in iteration i-1 (block i+1's data) have landed.
-template <bool DIV>
-__global__ void __launch_bounds__(256)
+// Fills and stores retire in issue order on one counter. In steady state every wave issues VEC fills
+// and one store per iteration, so at the wait of iteration i the fills issued in iteration
+// i-(DEPTH-1) -- block i+1's data -- are older than exactly 1 + (DEPTH-1)*(nfill+1) operations
+// (nfill = 1 when the second half of a VEC = 2 chunk lies entirely past Dp).
+template <int VEC, bool DIV, int AGG_DEPTH>   // AGG_DEPTH: ring fills run this many iterations ahead of their consumer
+__global__ void __launch_bounds__(AGG_WAVES * 64)
 k_agg_ring(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ arms,
            const uint32_t *__restrict__ cnt, int W, int H, int Dp, int vertical, int seglen, int cap, int rmask) {
-    extern __shared__ float ring[];  // (rmask+1) x 64
+    typedef typename VecT<VEC>::T vec_t;
+    constexpr int SLOT = 64 * VEC;          // floats per ring slot
+    constexpr int B = AGG_WAVES;
+    extern __shared__ __align__(16) float ring[];  // (rmask+1) x SLOT
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps span bounds in SGPRs
-    const int k = blockIdx.x * 64 + lane;
-    const bool kok = k < Dp;
+    const int kc = blockIdx.x * SLOT;       // first disparity of this workgroup's chunk
     const int line = blockIdx.y;
     const int LEN = vertical ? H : W;
     const int s0 = blockIdx.z * seglen;
     if (s0 >= LEN) return;
     const int s1 = min(LEN, s0 + seglen);
-    // Strides fit 32 bits (W*Dp < 2^31 is checked by the launcher); only base offsets are 64-bit. All
-    // per-iteration addresses are running pointers advanced by 32-bit strides: 64-bit multiplies on
-    // the scalar unit are what this kernel can least afford.
+    // Strides fit 32 bits (checked by the launcher); only base offsets are 64-bit. Per-iteration
+    // addresses are running pointers advanced by 32-bit strides: the scalar unit is shared by the
+    // whole CU and 64-bit multiplies on it are what this kernel can least afford.
     const int mstride = vertical ? W * Dp : Dp;          // elements between march positions
     const int astride = vertical ? W : 1;                // pixels between march positions
-    const size_t base = (vertical ? (size_t)line * Dp : (size_t)line * W * Dp) + (size_t)(kok ? k : 0);
+    const size_t lbase = (vertical ? (size_t)line * Dp : (size_t)line * W * Dp) + (size_t)kc;
     const size_t abase = vertical ? (size_t)line : (size_t)line * W;
     const int in_hi = min(LEN, s1 + cap);   // exclusive upper bound of input positions this segment needs
     const int sh_neg = vertical ? 16 : 0, sh_pos = vertical ? 24 : 8;
     const int R = rmask + 1;
-    const float *rl = ring + lane;
+    // fill addressing: lane <-> float `lane` (+64 for the second half) of the slot
+    bool fok[VEC];
+#pragma unroll
+    for (int h = 0; h < VEC; h++) fok[h] = kc + h * 64 + lane < Dp;
+    const int nfill = (VEC == 2 && kc + 64 >= Dp) ? 1 : VEC;   // fill instructions this workgroup's waves issue per position
+    const float *fsrc = src + lbase + lane;
+    // compute addressing: lane <-> floats lane*VEC .. lane*VEC+VEC-1 of the slot
+    const bool kok = kc + lane * VEC < Dp;  // Dp is a multiple of VEC
+    const float *rl = ring + lane * VEC;
 
-    // prologue: everything blocks 0 and 1 read, [max(0, s0-cap), min(in_hi, s0 + 2B + cap))
+    // prologue: everything blocks 0 .. DEPTH-1 read: [max(0, s0-cap), min(in_hi, s0 + DEPTH*B + cap))
     {
         const int lo = max(0, s0 - cap);
-        const int hi = min(in_hi, s0 + 2 * AGG_B + cap);
-        const float *g = src + base + (size_t)(lo + wave) * mstride;
-        for (int i = lo + wave; i < hi; i += 4, g += 4 * (ptrdiff_t)mstride)
-            if (kok) ring_fill(g, ring + (i & rmask) * 64);
+        const int hi = min(in_hi, s0 + AGG_DEPTH * B + cap);
+        const float *g = fsrc + (size_t)(lo + wave) * mstride;
+        for (int i = lo + wave; i < hi; i += B, g += (ptrdiff_t)B * mstride) {
+#pragma unroll
+            for (int h = 0; h < VEC; h++)
+                if (fok[h]) ring_fill(g + h * 64, ring + (i & rmask) * SLOT + h * 64);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
     // running pointers of this wave
-    const float *fill_p = src + base + (size_t)(s0 + 2 * AGG_B + cap + wave) * mstride;   // first fill of iteration 0
-    float *out_p = dst + base + (size_t)(s0 + wave * AGG_JB) * mstride;                    // first output of iteration 0
-    const uint32_t *arm_p = arms + abase + (size_t)(s0 + wave * AGG_JB) * astride;
-    const uint32_t *cnt_p = DIV ? cnt + abase + (size_t)(s0 + wave * AGG_JB) * astride : nullptr;
-    const ptrdiff_t blk_m = (ptrdiff_t)AGG_B * mstride, blk_a = (ptrdiff_t)AGG_B * astride;
+    const float *fill_p = fsrc + (size_t)(s0 + AGG_DEPTH * B + cap + wave) * mstride;   // this wave's fill of iteration 0
+    float *out_p = dst + lbase + lane * VEC + (size_t)(s0 + wave) * mstride;            // this wave's output of iteration 0
+    const uint32_t *arm_p = arms + abase + (size_t)(s0 + wave) * astride;
+    const uint32_t *cnt_p = DIV ? cnt + abase + (size_t)(s0 + wave) * astride : nullptr;
+    const ptrdiff_t blk_m = (ptrdiff_t)B * mstride, blk_a = (ptrdiff_t)B * astride;
 
-    // arms / support counts of a block are fetched (scalar loads) one iteration ahead of their use
-    uint32_t a_cur[AGG_JB], c_cur[AGG_JB];
-    {
-        const int last = max(0, s1 - 1 - (s0 + wave * AGG_JB));
-#pragma unroll
-        for (int j = 0; j < AGG_JB; j++) {
-            a_cur[j] = arm_p[min(j, last) * astride];
-            c_cur[j] = DIV ? cnt_p[min(j, last) * astride] : 1u;
-        }
+    // arms / support count of an output are fetched (scalar loads) one iteration ahead of their use
+    uint32_t a_cur = 0, c_cur = 1;
+    if (s0 + wave < s1) {
+        a_cur = arm_p[0];
+        if (DIV) c_cur = cnt_p[0];
     }
 
-    for (int o0 = s0; o0 < s1; o0 += AGG_B, fill_p += blk_m, out_p += blk_m, arm_p += blk_a, cnt_p += (DIV ? blk_a : 0)) {
-        // (a) fills for block i+2: positions [o0 + 2B + cap, o0 + 3B + cap); their slots are disjoint
-        //     from everything blocks i and i+1 read (2*cap + 3*B <= R)
-        const int n0 = o0 + 2 * AGG_B + cap;
+    for (int o0 = s0; o0 < s1; o0 += B, fill_p += blk_m, out_p += blk_m, arm_p += blk_a, cnt_p += (DIV ? blk_a : 0)) {
+        // (a) fill of the position block i+DEPTH adds to the window; its slot is not read by blocks i .. i+DEPTH-1
+        const int n0 = o0 + AGG_DEPTH * B + cap;
+        if (n0 + wave < in_hi) {
 #pragma unroll
-        for (int j = 0; j < AGG_B / 4; j++) {
-            const int i = n0 + wave + 4 * j;
-            if (i < in_hi && kok) ring_fill(fill_p + (ptrdiff_t)(4 * j) * mstride, ring + (i & rmask) * 64);
+            for (int h = 0; h < VEC; h++)
+                if (fok[h]) ring_fill(fill_p + h * 64, ring + ((n0 + wave) & rmask) * SLOT + h * 64);
         }
-        // (b) this wave's JB consecutive outputs
-        const int ob = o0 + wave * AGG_JB;
-        uint32_t a_nxt[AGG_JB], c_nxt[AGG_JB];
-#pragma unroll
-        for (int j = 0; j < AGG_JB; j++) { a_nxt[j] = 0; c_nxt[j] = 1u; }
-        if (ob + AGG_B < s1) {
-            const int lastn = s1 - 1 - (ob + AGG_B);
-#pragma unroll
-            for (int j = 0; j < AGG_JB; j++) {
-                a_nxt[j] = arm_p[blk_a + min(j, lastn) * astride];
-                c_nxt[j] = DIV ? cnt_p[blk_a + min(j, lastn) * astride] : 1u;
-            }
+        const int o = o0 + wave;
+        uint32_t a_nxt = 0, c_nxt = 1;
+        if (o + B < s1) {
+            a_nxt = arm_p[blk_a];
+            if (DIV) c_nxt = cnt_p[blk_a];
         }
-        if (ob < s1) {
-            const int last = s1 - 1 - ob;   // outputs past the segment repeat the last valid one (same value stored twice)
-            int st[AGG_JB], en[AGG_JB], jo[AGG_JB];
-            uint32_t cn[AGG_JB];
+        // (b) this wave's output
+        if (o < s1) {
+            const int neg = (a_cur >> sh_neg) & 0xff, pos = (a_cur >> sh_pos) & 0xff;
+            const int n = neg + pos + 1;
+            const int sl = (o - neg) & rmask;
+            const int n1 = min(n, R - sl);          // terms before the ring wraps
+            vec_t acc = {};
+            const float *q = rl + sl * SLOT;
+            int i = 0;
+            for (; i + 8 <= n1; i += 8) {
+                vec_t v[8];
 #pragma unroll
-            for (int j = 0; j < AGG_JB; j++) {
-                jo[j] = min(j, last);
-                const uint32_t a = a_cur[j];
-                st[j] = ob + jo[j] - (int)((a >> sh_neg) & 0xff);
-                en[j] = ob + jo[j] + (int)((a >> sh_pos) & 0xff);
-                cn[j] = c_cur[j];
+                for (int u = 0; u < 8; u++) v[u] = ring_read<vec_t>(q + (i + u) * SLOT);
+#pragma unroll
+                for (int u = 0; u < 8; u++) acc += v[u];
             }
-            const int lo = min(min(st[0], st[1]), min(st[2], st[3]));
-            const int hi = max(max(en[0], en[1]), max(en[2], en[3]));
-            int ca = max(max(st[0], st[1]), max(st[2], st[3]));   // first position inside every span
-            int cb = min(min(en[0], en[1]), min(en[2], en[3]));   // last position inside every span
-            if (ca > cb) { ca = hi + 1; cb = hi; }                // no common part: everything goes through the masked path
-            float sum[AGG_JB] = {0.0f, 0.0f, 0.0f, 0.0f};
-            // Range tests of the ragged parts run on the VALU: the position counter lives in a VGPR the
-            // compiler cannot prove uniform, so "is p inside span j" costs vector compares/selects instead
-            // of scalar-unit instructions (one scalar unit serves the whole CU and is the scarce resource here).
-            int pv;
-            asm volatile("v_mov_b32 %0, %1" : "=v"(pv) : "s"(lo));
-            uint32_t len[AGG_JB];
+            for (; i < n1; i++) acc += ring_read<vec_t>(q + i * SLOT);
+            const int n2 = n - n1;                  // terms after the wrap, from slot 0
+            i = 0;
+            for (; i + 8 <= n2; i += 8) {
+                vec_t v[8];
 #pragma unroll
-            for (int j = 0; j < AGG_JB; j++) len[j] = (uint32_t)(en[j] - st[j]);
-            // ragged head [lo, ca), four positions per trip so four LDS reads are in flight; a position at or
-            // past `ca` is turned into one that fails every range test
-            for (int p = lo; p < ca; p += 4, pv += 4) {
-                float v[4];
+                for (int u = 0; u < 8; u++) v[u] = ring_read<vec_t>(rl + (i + u) * SLOT);
 #pragma unroll
-                for (int u = 0; u < 4; u++) v[u] = rl[((p + u) & rmask) * 64];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int q = (pv + u < ca) ? pv + u : (int)0x80000000;
-#pragma unroll
-                    for (int j = 0; j < AGG_JB; j++) {
-                        const bool in = (uint32_t)(q - st[j]) <= len[j];
-                        sum[j] += in ? v[u] : 0.0f;
-                    }
-                }
+                for (int u = 0; u < 8; u++) acc += v[u];
             }
-            // common part, in at most two runs that do not wrap around the ring
-            for (int p = ca; p <= cb;) {
-                const int sl = p & rmask;
-                const int run = min(cb - p + 1, R - sl);
-                const float *q = rl + sl * 64;
-                int i = 0;
-                for (; i + 4 <= run; i += 4) {
-                    const float v0 = q[(i + 0) * 64], v1 = q[(i + 1) * 64], v2 = q[(i + 2) * 64], v3 = q[(i + 3) * 64];
-#pragma unroll
-                    for (int j = 0; j < AGG_JB; j++) sum[j] += v0;
-#pragma unroll
-                    for (int j = 0; j < AGG_JB; j++) sum[j] += v1;
-#pragma unroll
-                    for (int j = 0; j < AGG_JB; j++) sum[j] += v2;
-#pragma unroll
-                    for (int j = 0; j < AGG_JB; j++) sum[j] += v3;
-                }
-                for (; i < run; i++) {
-                    const float v = q[i * 64];
-#pragma unroll
-                    for (int j = 0; j < AGG_JB; j++) sum[j] += v;
-                }
-                p += run;
-            }
-            // ragged tail (cb, hi], same scheme
-            asm volatile("v_mov_b32 %0, %1" : "=v"(pv) : "s"(cb + 1));
-            for (int p = cb + 1; p <= hi; p += 4, pv += 4) {
-                float v[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) v[u] = rl[((p + u) & rmask) * 64];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int q = (pv + u <= hi) ? pv + u : (int)0x80000000;
-#pragma unroll
-                    for (int j = 0; j < AGG_JB; j++) {
-                        const bool in = (uint32_t)(q - st[j]) <= len[j];
-                        sum[j] += in ? v[u] : 0.0f;
-                    }
-                }
-            }
-            // always JB store instructions per wave, so the number of operations younger than last
-            // iteration's fills is fixed
-#pragma unroll
-            for (int j = 0; j < AGG_JB; j++) {
-                float r = sum[j];
-                if (DIV) r = r / (float)cn[j];
-                if (kok) out_p[(ptrdiff_t)jo[j] * mstride] = r;
-            }
+            for (; i < n2; i++) acc += ring_read<vec_t>(rl + i * SLOT);
+            if (DIV) acc = acc / (float)c_cur;
+            if (kok) *reinterpret_cast<vec_t *>(out_p) = acc;
         }
-#pragma unroll
-        for (int j = 0; j < AGG_JB; j++) { a_cur[j] = a_nxt[j]; c_cur[j] = c_nxt[j]; }
-        // (c) block i+1's fills (issued one iteration ago) must have landed before anyone reads them.
-        //     Once this iteration issued fewer than 4 fills (end of the line / segment) the count of
-        //     younger operations is no longer fixed: drain instead.
-        if (n0 + AGG_B > in_hi) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        a_cur = a_nxt;
+        c_cur = c_nxt;
+        // (c) block i+1's fills must have landed before anyone reads them. Once a wave skipped a fill
+        //     (end of the line / segment) the count of younger operations is no longer fixed: drain.
+        if (n0 + B > in_hi) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (nfill == VEC) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 + (AGG_DEPTH - 1) * (VEC + 1)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 + (AGG_DEPTH - 1) * 2) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
@@ -229,7 +178,7 @@ __global__ void __launch_bounds__(256)
 k_agg_direct(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ arms,
              const uint32_t *__restrict__ cnt, int W, int H, int Dp, int vertical) {
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps span bounds in SGPRs
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int k = blockIdx.x * 64 + lane;
     const bool kok = k < Dp;
     const int line = blockIdx.y;
@@ -241,7 +190,7 @@ k_agg_direct(const float *__restrict__ src, float *__restrict__ dst, const uint3
     const int sh_neg = vertical ? 16 : 0, sh_pos = vertical ? 24 : 8;
     for (int o = blockIdx.z * 4 + wave; o < LEN; o += 4 * gridDim.z) {
         const size_t ap = abase + (size_t)o * astride;
-        const uint32_t a = __builtin_amdgcn_readfirstlane(arms[ap]);
+        const uint32_t a = arms[ap];
         const int neg = (a >> sh_neg) & 0xff, pos = (a >> sh_pos) & 0xff;
         float sum = 0.0f;
         if (kok) {
@@ -256,29 +205,57 @@ k_agg_direct(const float *__restrict__ src, float *__restrict__ dst, const uint3
     }
 }
 
-void launch_aggregate_pass(const float *src, float *dst, const uint32_t *arms, const uint32_t *cnt,
-                           const Geom &g, int vertical, int max_arm, int variant, hipStream_t s) {
-    const int chunks = (g.Dp + 63) / 64;
+template <int VEC, int DEPTH>
+static void launch_ring(const float *src, float *dst, const uint32_t *arms, const uint32_t *cnt, const Geom &g,
+                        int vertical, int max_arm, int R, hipStream_t s) {
+    const int SLOT = 64 * VEC;
+    const int chunks = (g.Dp + SLOT - 1) / SLOT;
     const int lines = vertical ? g.W : g.H;
     const int LEN = vertical ? g.H : g.W;
-    int R = 64;
-    while (R < 2 * max_arm + 1 + 3 * AGG_B) R <<= 1;
-    const size_t lds = (size_t)R * 64 * sizeof(float);
-    if (variant == 0 && lds <= 64 * 1024) {
-        // enough workgroups to fill 256 CUs several times over; segments are multiples of AGG_B
-        int nseg = 1;
-        const long long wgs = (long long)chunks * lines;
-        if (wgs < 2048) nseg = (int)((2048 + wgs - 1) / wgs);
-        int seglen = (LEN + nseg - 1) / nseg;
-        seglen = ((seglen + AGG_B - 1) / AGG_B) * AGG_B;
-        if (seglen < 4 * AGG_B) seglen = 4 * AGG_B;
-        nseg = (LEN + seglen - 1) / seglen;
-        dim3 grid(chunks, lines, nseg);
-        if (cnt)
-            k_agg_ring<true><<<grid, dim3(256), lds, s>>>(src, dst, arms, cnt, g.W, g.H, g.Dp, vertical, seglen, max_arm, R - 1);
-        else
-            k_agg_ring<false><<<grid, dim3(256), lds, s>>>(src, dst, arms, cnt, g.W, g.H, g.Dp, vertical, seglen, max_arm, R - 1);
+    const size_t lds = (size_t)R * SLOT * sizeof(float);
+    // enough workgroups for several full rounds over 256 CUs; segments are multiples of the block size
+    int nseg = 1;
+    const long long wgs = (long long)chunks * lines;
+    if (wgs < 4096) nseg = (int)((4096 + wgs - 1) / wgs);
+    int seglen = (LEN + nseg - 1) / nseg;
+    seglen = ((seglen + AGG_WAVES - 1) / AGG_WAVES) * AGG_WAVES;
+    if (seglen < 128) seglen = 128;
+    nseg = (LEN + seglen - 1) / seglen;
+    dim3 grid(chunks, lines, nseg), block(AGG_WAVES * 64);
+    static bool attr_set = false;   // per template instance: allow the full 64 KB of dynamic LDS
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_agg_ring<VEC, true, DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_agg_ring<VEC, false, DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        attr_set = true;
+    }
+    if (cnt)
+        k_agg_ring<VEC, true, DEPTH><<<grid, block, lds, s>>>(src, dst, arms, cnt, g.W, g.H, g.Dp, vertical, seglen, max_arm, R - 1);
+    else
+        k_agg_ring<VEC, false, DEPTH><<<grid, block, lds, s>>>(src, dst, arms, cnt, g.W, g.H, g.Dp, vertical, seglen, max_arm, R - 1);
+}
+
+void launch_aggregate_pass(const float *src, float *dst, const uint32_t *arms, const uint32_t *cnt,
+                           const Geom &g, int vertical, int max_arm, int variant, hipStream_t s) {
+    // deepest fill look-ahead (6, 4 or 2 iterations) whose ring still fits 64 KB of LDS
+    static const int depth_env = std::getenv("ADC_AGG_DEPTH") ? std::atoi(std::getenv("ADC_AGG_DEPTH")) : 6;
+    const bool strides_ok = (long long)g.W * g.Dp * (AGG_WAVES + 1) < (1ll << 31);
+    const int vec = (g.Dp >= 128 && g.Dp % 2 == 0) ? 2 : 1;
+    int depth = 0, R = 0;
+    for (int d : {6, 4, 2}) {
+        if (d > depth_env) continue;
+        int r = 64;
+        while (r < 2 * max_arm + (d + 1) * AGG_WAVES) r <<= 1;
+        if ((size_t)r * 64 * vec * 4 <= 64 * 1024) { depth = d; R = r; break; }
+    }
+    if (variant == 0 && strides_ok && depth) {
+#define ADC_RING(V, D) launch_ring<V, D>(src, dst, arms, cnt, g, vertical, max_arm, R, s)
+        if (vec == 2) { if (depth == 6) ADC_RING(2, 6); else if (depth == 4) ADC_RING(2, 4); else ADC_RING(2, 2); }
+        else { if (depth == 6) ADC_RING(1, 6); else if (depth == 4) ADC_RING(1, 4); else ADC_RING(1, 2); }
+#undef ADC_RING
     } else {
+        const int chunks = (g.Dp + 63) / 64;
+        const int lines = vertical ? g.W : g.H;
+        const int LEN = vertical ? g.H : g.W;
         int nz = 1;
         const long long wgs = (long long)chunks * lines;
         if (wgs < 4096) nz = (int)((4096 + wgs - 1) / wgs);
