@@ -163,6 +163,10 @@ int do_initialize(adc_handle *h, int32_t W, int32_t H, const adc_option *opt) {
     A(h->pl.cen_l, npx); A(h->pl.cen_r, npx);
     A(h->pl.step_l, npx); A(h->pl.step_r, npx);
     A(h->pl.arms, npx); A(h->pl.cnt_h, npx); A(h->pl.cnt_v, npx); A(h->pl.cnt_h32, npx); A(h->pl.cnt_v32, npx);
+    {
+        const size_t nrec = npx * (size_t)(2 * g.NV + 1);
+        A(h->pl.rec_hf, nrec); A(h->pl.rec_hb, nrec); A(h->pl.rec_v, nrec);
+    }
     A(h->vol_a, nvol); A(h->vol_b, nvol);
     A(h->lut_ad, 768); A(h->lut_cen, 68);
     A(h->disp_a, npx); A(h->disp_b, npx); A(h->disp_r, npx); A(h->disp_final, npx);
@@ -259,6 +263,7 @@ int enqueue_match(adc_handle *h, const uint8_t *d_l, const uint8_t *d_r, float *
     launch_step_flags(pl.pix_r, pl.step_r, g.W, g.H, o.so_tso, s);
     launch_arms(pl.pix_l, pl.arms, g.W, g.H, o.cross_L1, o.cross_L2, o.cross_t1, o.cross_t2, s);
     launch_sup_counts(pl.arms, pl.cnt_h, pl.cnt_v, pl.cnt_h32, pl.cnt_v32, g.W, g.H, s);
+    launch_scan_records(pl, g, s);
 
     mark(ADC_STAGE_COST);
     launch_cost_init(pl, g, h->lut_ad, h->lut_cen, h->vol_b, s);

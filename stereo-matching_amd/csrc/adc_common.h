@@ -31,6 +31,7 @@ struct Planes {
     uint32_t *arms;                 // left | right<<8 | top<<16 | bottom<<24
     uint16_t *cnt_h, *cnt_v;
     uint32_t *cnt_h32, *cnt_v32;    // same counts widened to 32 bits (dword scalar loads in the aggregation kernel)
+    uint32_t *rec_hf, *rec_hb, *rec_v;  // per-pixel colour-step records of the scanline passes, (2*NV+1) dwords each
 };
 
 // --- adc_pre.hip -------------------------------------------------------------------------------
@@ -55,6 +56,7 @@ void launch_aggregate_pass(const float *src, float *dst, const uint32_t *arms, c
 // One directional scanline pass (src -> dst). Ptab = {P1[0..2], P2[0..2]} indexed by how many of
 // (d1,d2) reach tso.
 struct ScanParams { float P1[3]; float P2[3]; };
+void launch_scan_records(const Planes &p, const Geom &g, hipStream_t s);
 void launch_scanline_pass(const float *src, float *dst, const Planes &p, const Geom &g,
                           const ScanParams &sp, int vertical, int forward, hipStream_t s);
 

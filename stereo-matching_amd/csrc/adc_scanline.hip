@@ -4,7 +4,7 @@
 // One wavefront owns one scanline (a row for the horizontal passes, a column for the vertical ones)
 // and walks it sequentially. The D path costs of the current pixel live in registers, NV per lane
 // with lane l holding disparities l*NV .. l*NV+NV-1, so
-//   * the load/store of a pixel's disparity vector is one contiguous NV*256-byte access,
+//   * a pixel's disparity vector moves as one contiguous NV*256-byte access,
 //   * Lr(p-r, d-1) / Lr(p-r, d+1) are register neighbours except at lane boundaries, where one DPP
 //     wave shift per direction supplies them (lanes past D hold Large_Float = the reference's
 //     sentinels Lp[-1], Lp[D]),
@@ -14,10 +14,75 @@
 //   dst[p][d] = (src[p][d] + min(Lp[d], Lp[d-1]+P1, Lp[d+1]+P1, min(Lp)+P2)) / 2
 // (P1,P2) chosen by how many of the two colour steps reach so_tso (:97-109); first path pixel
 // copies src (:51-52).
+//
+// A scanline is a serial chain with only ~1-2 waves per SIMD to run it, so HBM latency has to be
+// hidden inside the wave: every path pixel's cost vector and its colour-step record are brought in
+// by LDS-DMA into a per-wave ring RS pixels ahead of their use, with counted vmcnt waits.
 #include "adc_common.h"
 
 namespace adc {
 
+// ---- colour-step records ----------------------------------------------------------------------------
+// For every pixel p and every disparity k the recurrence needs one bit: does d2 reach so_tso
+// (ADC/scanline_optimizer.cu:75-109)? d2 is the colour step of the RIGHT image at xr = x - k - dmin
+// along the path when 0 < xr < W-1, keeps the value of the previous disparity otherwise, and starts
+// as d1 (the LEFT image step). As k grows xr only decreases, so "previous value" is: d1 while
+// xr >= W-1 (nothing usable yet), and the step at xr = 1 once xr <= 0 -- or d1 for every k when not
+// even k = 0 reaches a usable column. All of this depends on the pixel only, so it is baked once per
+// frame into a record per pixel: 2*NV dwords of bits (bit k of the record = effective d2 flag) + one
+// dword whose bit 0 is the d1 flag. One table per path family: horizontal forward, horizontal
+// backward, vertical (the backward vertical pass reads the record one row further down, because the
+// pair (y, y+1) is stored at y+1).
+__global__ void __launch_bounds__(256)
+k_scan_records(const uint8_t *__restrict__ step_l, const uint8_t *__restrict__ step_r, uint32_t *__restrict__ rec_hf,
+               uint32_t *__restrict__ rec_hb, uint32_t *__restrict__ rec_v, int W, int H, int dmin, int D, int recw) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)W * H * recw;
+    if (gid >= total) return;
+    const size_t p = gid / recw;
+    const int w = (int)(gid - p * recw);
+    const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
+    const uint8_t *rrow = step_r + (size_t)y * W;
+    const uint32_t f1_hf = step_l[p] & 1u;
+    const uint32_t f1_hb = (x + 1 < W) ? (step_l[p + 1] & 1u) : 0u;
+    const uint32_t f1_v = (step_l[p] >> 1) & 1u;
+    if (w == recw - 1) {
+        rec_hf[gid] = f1_hf;
+        rec_hb[gid] = f1_hb;
+        rec_v[gid] = f1_v;
+        return;
+    }
+    const bool none = (x - dmin < 1) || (W < 3);   // no disparity of this pixel has 0 < xr < W-1
+    uint32_t b_hf = 0, b_hb = 0, b_v = 0;
+    for (int b = 0; b < 32; b++) {
+        const int k = w * 32 + b;
+        if (k >= D) break;
+        const int xe = x - dmin - k;
+        uint32_t e_hf = f1_hf, e_hb = f1_hb, e_v = f1_v;
+        if (!(none || xe >= W - 1)) {
+            const int xc = min(max(xe, 1), W - 2);
+            const uint32_t s0 = rrow[xc], s1 = rrow[xc + 1];
+            e_hf = s0 & 1u;          // step between right pixels xc and xc-1
+            e_hb = s1 & 1u;          // step between right pixels xc and xc+1
+            e_v = (s0 >> 1) & 1u;    // step between rows y and y-1 at column xc
+        }
+        b_hf |= e_hf << b;
+        b_hb |= e_hb << b;
+        b_v |= e_v << b;
+    }
+    rec_hf[gid] = b_hf;
+    rec_hb[gid] = b_hb;
+    rec_v[gid] = b_v;
+}
+
+void launch_scan_records(const Planes &p, const Geom &g, hipStream_t s) {
+    const int recw = 2 * g.NV + 1;
+    const size_t total = (size_t)g.W * g.H * recw;
+    k_scan_records<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(p.step_l, p.step_r, p.rec_hf, p.rec_hb, p.rec_v,
+                                                                             g.W, g.H, g.dmin, g.D, recw);
+}
+
+// ---- the pass ----------------------------------------------------------------------------------------
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float old, float src) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xf, 0xf, false));
@@ -62,145 +127,219 @@ __device__ __forceinline__ void store_vec(float *p, const float (&v)[NV]) {
     }
 }
 
-#define SCAN_U 4  // path pixels whose loads are in flight together
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <typename T>
+__device__ __forceinline__ T lds_read(uint32_t byte_off) {
+    typedef const volatile T __attribute__((address_space(3))) *lds_ptr;
+    return *(lds_ptr)(uintptr_t)byte_off;
+}
+template <int NV>
+__device__ __forceinline__ void lds_read_vec(uint32_t byte_off, float (&v)[NV]) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    if constexpr (NV == 1) {
+        v[0] = lds_read<float>(byte_off);
+    } else if constexpr (NV == 2) {
+        const f2 t = lds_read<f2>(byte_off);
+        v[0] = t.x; v[1] = t.y;
+    } else {
+#pragma unroll
+        for (int q = 0; q < NV / 4; q++) {
+            const f4 t = lds_read<f4>(byte_off + 16 * q);
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+    }
+}
+
+template <int NV> struct ScanCfg {
+    static constexpr int DATA_B = 256 * NV;                         // one pixel's cost vector
+    static constexpr int FLAG_B = ((8 * NV + 4 + 15) / 16) * 16;    // its colour-step record, padded to 16 B
+    static constexpr int SLOT_B = DATA_B + FLAG_B;
+    static constexpr int NDMA = NV >= 4 ? NV / 4 : NV;              // LDS-DMA instructions per cost vector
+    static constexpr int NST = NV >= 4 ? NV / 4 : 1;                // store instructions per cost vector
+    static constexpr int RS = NV <= 4 ? 16 : (NV == 8 ? 8 : 4);     // ring slots per wave (~17 KB)
+    // operations younger than the fill of step s+1 at the point step s waits for it (see the loop)
+    static constexpr int WAITN = (RS - 2) * (NDMA + 1 + NST);
+    static_assert(WAITN <= 63, "vmcnt is a 6-bit counter");
+};
 
 // VERT = 0: wave walks row `line` along x; VERT = 1: walks column `line` along y.
-template <int NV, int VERT>
+// FULL: Dp == D == 64*NV, every lane owns NV real disparities (no masking anywhere).
+template <int NV, int VERT, bool FULL>
 __global__ void __launch_bounds__(256)
-k_scanline(const float *__restrict__ src, float *__restrict__ dst, const uint8_t *__restrict__ step_l,
-           const uint8_t *__restrict__ step_r, int W, int H, int dmin, int D, int Dp, int forward, ScanParams sp) {
+k_scanline(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ rec,
+           int W, int H, int D, int Dp, int forward, ScanParams sp) {
+    typedef ScanCfg<NV> C;
+    extern __shared__ __align__(16) uint8_t lds_raw[];
     const int lane = threadIdx.x & 63;
-    const int line = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int line = blockIdx.x * 4 + wave;
     const int nlines = VERT ? W : H;
     if (line >= nlines) return;
+    uint8_t *ring = lds_raw + (size_t)wave * C::RS * C::SLOT_B;
     const int LEN = VERT ? H : W;
     const int dir = forward ? 1 : -1;
     const int k0 = lane * NV;
-    const bool active = k0 < Dp;              // lane owns part of the (padded) disparity vector
+    const bool active = FULL || k0 < Dp;       // lane owns part of the (padded) disparity vector
     const int koff = active ? k0 : 0;
-    // position of the path head and per-step strides
-    int x = VERT ? line : (forward ? 0 : W - 1);
-    int y = VERT ? (forward ? 0 : H - 1) : line;
-    const ptrdiff_t pstep = VERT ? (ptrdiff_t)dir * W : (ptrdiff_t)dir;   // in pixels
-    ptrdiff_t pix = (ptrdiff_t)y * W + x;
+    const int recw = 2 * NV + 1;
+    // path head, per-step strides (in pixels), and the record shift of the backward vertical pass
+    const int x0 = VERT ? line : (forward ? 0 : W - 1);
+    const int y0 = VERT ? (forward ? 0 : H - 1) : line;
+    const ptrdiff_t pstep = VERT ? (ptrdiff_t)dir * W : (ptrdiff_t)dir;
+    const ptrdiff_t pix0 = (ptrdiff_t)y0 * W + x0;
+    const ptrdiff_t rshift = (VERT && !forward) ? (ptrdiff_t)W : 0;
 
+    // ---- fill addressing (lane <-> DMA element, which differs from the compute mapping for NV < 4)
+    // data: NV >= 4: instruction q moves floats q*256 + 4*lane .. +3 (16 B per lane);
+    //       NV <  4: instruction h moves float h*64 + lane (4 B per lane)
+    const float *gfill = src + (NV >= 4 ? 4 * lane : lane);
+    bool fok[C::NDMA];
+#pragma unroll
+    for (int q = 0; q < C::NDMA; q++) fok[q] = FULL || ((NV >= 4 ? q * 256 + 4 * lane : q * 64 + lane) < Dp);
+    // the counted wait below assumes every one of the NDMA fill instructions has at least one live lane
+    const bool counted = FULL || (Dp > (C::NDMA - 1) * (NV >= 4 ? 256 : 64));
+    const uint32_t *gflag = rec + lane;
+    const bool flag_lane = lane < recw;
+
+    auto issue_fill = [&](int s) {     // path pixel s -> ring slot s % RS
+        const ptrdiff_t p = pix0 + (ptrdiff_t)s * pstep;
+        uint8_t *slot = ring + (s % C::RS) * C::SLOT_B;
+        const float *g = gfill + (size_t)p * Dp;
+#pragma unroll
+        for (int q = 0; q < C::NDMA; q++) {
+            if (fok[q]) {
+                if constexpr (NV >= 4)
+                    __builtin_amdgcn_global_load_lds(g + q * 256, (lds_void *)(slot + q * 1024), 16, 0, 0);
+                else
+                    __builtin_amdgcn_global_load_lds(g + q * 64, (lds_void *)(slot + q * 256), 4, 0, 0);
+            }
+        }
+        if (flag_lane)
+            __builtin_amdgcn_global_load_lds(gflag + (size_t)(p + rshift) * recw, (lds_void *)(slot + C::DATA_B), 4, 0, 0);
+    };
+    // compute-side view of a slot. The reads go through an LDS address rebuilt from an integer: the
+    // compiler then has no basis to tie them to the in-flight LDS-DMA fills (it would otherwise put a
+    // full vmcnt(0) in front of every ring read); ordering is what the counted waits in the loop provide.
+    const uint32_t ring_off = (uint32_t)(uintptr_t)ring;
+    auto read_slot = [&](int s, float (&v)[NV], uint32_t &bits, uint32_t &f1) {
+        const uint32_t slot = ring_off + (uint32_t)(s % C::RS) * C::SLOT_B;
+        lds_read_vec<NV>(slot + (uint32_t)k0 * 4, v);
+        if constexpr (NV == 16) bits = lds_read<uint16_t>(slot + C::DATA_B + 2 * lane);
+        else bits = (uint32_t)lds_read<uint8_t>(slot + C::DATA_B + ((lane * NV) >> 3)) >> ((lane * NV) & 7);
+        f1 = lds_read<uint32_t>(slot + C::DATA_B + 8 * NV) & 1u;
+    };
+
+    // ---- path head: dst = src, Lp = src
     float Lp[NV];
     {
         float s[NV];
-        if (active) load_vec<NV>(src + (size_t)pix * Dp + koff, s);
 #pragma unroll
-        for (int j = 0; j < NV; j++) Lp[j] = (active && k0 + j < D) ? s[j] : ADC_LARGE_F;
+        for (int j = 0; j < NV; j++) s[j] = 0.0f;
+        if (active) load_vec<NV>(src + (size_t)pix0 * Dp + koff, s);
+#pragma unroll
+        for (int j = 0; j < NV; j++) Lp[j] = (active && (FULL || k0 + j < D)) ? s[j] : ADC_LARGE_F;
         if (active) {
             float o[NV];
 #pragma unroll
-            for (int j = 0; j < NV; j++) o[j] = (k0 + j < D) ? s[j] : 0.0f;
-            store_vec<NV>(dst + (size_t)pix * Dp + koff, o);
+            for (int j = 0; j < NV; j++) o[j] = (FULL || k0 + j < D) ? s[j] : 0.0f;
+            store_vec<NV>(dst + (size_t)pix0 * Dp + koff, o);
         }
     }
     float lmin = Lp[0];
 #pragma unroll
     for (int j = 1; j < NV; j++) lmin = fminf(lmin, Lp[j]);
     float minLp = wave_min(lmin);
+    if (LEN < 2) return;
 
-    // Colour-step flag of the pair (current, previous path pixel) is stored at the pixel with the
-    // larger coordinate: bit0 for horizontal pairs, bit1 for vertical pairs.
-    const int fbit = VERT ? 1 : 0;
-    const ptrdiff_t fshift = forward ? 0 : (VERT ? (ptrdiff_t)W : (ptrdiff_t)1);  // backward: pair stored one pixel further
+    // ---- prologue: fills of path pixels 1 .. RS-1, all landed, pixel 1 in registers
+    for (int t = 1; t < C::RS && t < LEN; t++) issue_fill(t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float cur[NV];
+    uint32_t cbits, cf1;
+    read_slot(1, cur, cbits, cf1);
 
-    for (int st0 = 1; st0 < LEN; st0 += SCAN_U) {
-        float s[SCAN_U][NV];
-        uint32_t f2[SCAN_U];
-        uint32_t f1v = 0;
-        // ---- issue every load of this group first
+    float *outp = dst + (size_t)(pix0 + pstep) * Dp + koff;
+    const ptrdiff_t ostep = pstep * (ptrdiff_t)Dp;
+    for (int s = 1; s < LEN; s++, outp += ostep) {
+        // (A) fill of pixel s+RS-1 into the slot pixel s-1 occupied (its reads completed an iteration ago)
+        const int t = s + C::RS - 1;
+        if (t < LEN) issue_fill(t);
+        // (B) pixel s+1 must have landed. In steady state the operations issued after its fill are
+        //     (RS-2) x (fill + store) groups -- exactly WAITN; near the end of the path that count shrinks,
+        //     so drain instead.
+        if (t < LEN && counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::WAITN) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (C) start reading pixel s+1 while pixel s is computed
+        float nxt[NV];
+        uint32_t nbits = 0, nf1 = 0;
 #pragma unroll
-        for (int u = 0; u < SCAN_U; u++) {
-            const bool ok = st0 + u < LEN;
-            const ptrdiff_t pu = pix + (ptrdiff_t)(u + 1) * pstep;
-            if (ok && active) load_vec<NV>(src + (size_t)pu * Dp + koff, s[u]);
-            else {
+        for (int j = 0; j < NV; j++) nxt[j] = 0.0f;
+        if (s + 1 < LEN) read_slot(s + 1, nxt, nbits, nf1);
+        // (D) the recurrence for pixel s
+        const float P1a = cf1 ? sp.P1[1] : sp.P1[0], P1b = cf1 ? sp.P1[2] : sp.P1[1];
+        const float P2a = cf1 ? sp.P2[1] : sp.P2[0], P2b = cf1 ? sp.P2[2] : sp.P2[1];
+        const float up = dpp_f<0x138>(ADC_LARGE_F, Lp[NV - 1]);  // wave_shr:1 -> Lp[k0-1]
+        const float dn = dpp_f<0x130>(ADC_LARGE_F, Lp[0]);       // wave_shl:1 -> Lp[k0+NV]
+        const float l4a = minLp + P2a, l4b = minLp + P2b;
+        float nw[NV];
+        float lm = ADC_LARGE_F;
 #pragma unroll
-                for (int j = 0; j < NV; j++) s[u][j] = 0.0f;
-            }
-            // right-image flags for this lane's disparities at path pixel pu
-            uint32_t bits = 0;
-            if (ok) {
-                const int xu = VERT ? x : x + (u + 1) * dir;
-                const int yu = VERT ? y + (u + 1) * dir : y;
-                const bool none = (xu - dmin < 1) || (W < 3);   // no disparity of this pixel has 0 < xr < W-1
-                const uint8_t *row = step_r + (ptrdiff_t)yu * W + fshift;
-#pragma unroll
-                for (int j = 0; j < NV; j++) {
-                    const int xe = xu - dmin - (k0 + j);
-                    // xr >= W-1 happens only before the first usable disparity: d2 is still d1 there.
-                    // xr <= 0 keeps the flag of the last usable disparity, whose xr is 1.
-                    const bool use_f1 = none || xe >= W - 1;
-                    const int xc = max(xe, 1);
-                    uint32_t b = 2;  // 2 = "same as d1"
-                    if (!use_f1) b = (row[min(xc, W - 2)] >> fbit) & 1u;
-                    bits |= b << (2 * j);
-                }
-            }
-            f2[u] = bits;
+        for (int j = 0; j < NV; j++) {
+            const bool hi = (cbits >> j) & 1u;
+            const float P1 = hi ? P1b : P1a;
+            const float l1 = Lp[j];
+            const float l2 = (j == 0 ? up : Lp[j - 1]) + P1;
+            const float l3 = (j == NV - 1 ? dn : Lp[j + 1]) + P1;
+            const float l4 = hi ? l4b : l4a;
+            const float m = fminf(fminf(l1, l2), fminf(l3, l4));
+            const float v = (cur[j] + m) / 2.0f;
+            nw[j] = (FULL || (active && k0 + j < D)) ? v : ADC_LARGE_F;
+            lm = fminf(lm, nw[j]);
         }
-        // left-image flags of the group: lane u fetches the one for step u
-        {
-            const int u = lane & (SCAN_U - 1);
-            if (st0 + u < LEN) {
-                const ptrdiff_t pu = pix + (ptrdiff_t)(u + 1) * pstep;
-                f1v = (step_l[pu + fshift] >> fbit) & 1u;
-            }
+        if (active) {
+            float o[NV];
+#pragma unroll
+            for (int j = 0; j < NV; j++) o[j] = (FULL || k0 + j < D) ? nw[j] : 0.0f;
+            store_vec<NV>(outp, o);
         }
-        // ---- sequential recurrence over the group
 #pragma unroll
-        for (int u = 0; u < SCAN_U; u++) {
-            if (st0 + u >= LEN) break;
-            const uint32_t f1 = __builtin_amdgcn_readlane(f1v, u);
-            const float P1a = f1 ? sp.P1[1] : sp.P1[0], P1b = f1 ? sp.P1[2] : sp.P1[1];
-            const float P2a = f1 ? sp.P2[1] : sp.P2[0], P2b = f1 ? sp.P2[2] : sp.P2[1];
-            const float up = dpp_f<0x138>(ADC_LARGE_F, Lp[NV - 1]);  // wave_shr:1 -> Lp[k0-1]
-            const float dn = dpp_f<0x130>(ADC_LARGE_F, Lp[0]);       // wave_shl:1 -> Lp[k0+NV]
-            float nw[NV];
-            float lm = ADC_LARGE_F;
+        for (int j = 0; j < NV; j++) Lp[j] = nw[j];
+        minLp = wave_min(lm);
+        // (E)
 #pragma unroll
-            for (int j = 0; j < NV; j++) {
-                const uint32_t b = (f2[u] >> (2 * j)) & 3u;
-                const bool hi = (b == 2u) ? (f1 != 0) : (b != 0);
-                const float P1 = hi ? P1b : P1a;
-                const float P2 = hi ? P2b : P2a;
-                const float l1 = Lp[j];
-                const float l2 = (j == 0 ? up : Lp[j - 1]) + P1;
-                const float l3 = (j == NV - 1 ? dn : Lp[j + 1]) + P1;
-                const float l4 = minLp + P2;
-                const float m = fminf(fminf(l1, l2), fminf(l3, l4));
-                const float v = (s[u][j] + m) / 2.0f;
-                nw[j] = (active && k0 + j < D) ? v : ADC_LARGE_F;
-                lm = fminf(lm, nw[j]);
-            }
-            const ptrdiff_t pu = pix + (ptrdiff_t)(u + 1) * pstep;
-            if (active) {
-                float o[NV];
-#pragma unroll
-                for (int j = 0; j < NV; j++) o[j] = (k0 + j < D) ? nw[j] : 0.0f;
-                store_vec<NV>(dst + (size_t)pu * Dp + koff, o);
-            }
-#pragma unroll
-            for (int j = 0; j < NV; j++) Lp[j] = nw[j];
-            minLp = wave_min(lm);
-        }
-        pix += (ptrdiff_t)SCAN_U * pstep;
-        if (VERT) y += SCAN_U * dir; else x += SCAN_U * dir;
+        for (int j = 0; j < NV; j++) cur[j] = nxt[j];
+        cbits = nbits;
+        cf1 = nf1;
     }
 }
 
 template <int NV>
 static void launch_nv(const float *src, float *dst, const Planes &p, const Geom &g, const ScanParams &sp,
                       int vertical, int forward, hipStream_t s) {
+    typedef ScanCfg<NV> C;
     const int nlines = vertical ? g.W : g.H;
-    dim3 grid((nlines + 3) / 4);
-    if (vertical)
-        k_scanline<NV, 1><<<grid, dim3(256), 0, s>>>(src, dst, p.step_l, p.step_r, g.W, g.H, g.dmin, g.D, g.Dp, forward, sp);
-    else
-        k_scanline<NV, 0><<<grid, dim3(256), 0, s>>>(src, dst, p.step_l, p.step_r, g.W, g.H, g.dmin, g.D, g.Dp, forward, sp);
+    dim3 grid((nlines + 3) / 4), block(256);
+    const size_t lds = (size_t)4 * C::RS * C::SLOT_B;
+    const bool full = (g.D == 64 * NV) && (g.Dp == g.D);
+    const uint32_t *rec = vertical ? p.rec_v : (forward ? p.rec_hf : p.rec_hb);
+    static bool attr_set = false;
+    if (!attr_set) {
+        const int cap = 96 * 1024;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scanline<NV, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scanline<NV, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scanline<NV, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scanline<NV, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        attr_set = true;
+    }
+    if (vertical) {
+        if (full) k_scanline<NV, 1, true><<<grid, block, lds, s>>>(src, dst, rec, g.W, g.H, g.D, g.Dp, forward, sp);
+        else k_scanline<NV, 1, false><<<grid, block, lds, s>>>(src, dst, rec, g.W, g.H, g.D, g.Dp, forward, sp);
+    } else {
+        if (full) k_scanline<NV, 0, true><<<grid, block, lds, s>>>(src, dst, rec, g.W, g.H, g.D, g.Dp, forward, sp);
+        else k_scanline<NV, 0, false><<<grid, block, lds, s>>>(src, dst, rec, g.W, g.H, g.D, g.Dp, forward, sp);
+    }
 }
 
 void launch_scanline_pass(const float *src, float *dst, const Planes &p, const Geom &g,
