@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libadcensus_hip.so")
+LIB_PATH = os.environ.get("ADC_LIB_PATH") or os.path.join(_HERE, "lib", "libadcensus_hip.so")  # override: A/B builds
 
 ADC_OK, ADC_ERR_ARG, ADC_ERR_NOT_INIT, ADC_ERR_HIP, ADC_ERR_UNSUPPORTED, ADC_ERR_NOMEM = range(6)
 

@@ -23,7 +23,12 @@
 
 namespace adc {
 
+#ifndef AGG_WAVES
 #define AGG_WAVES 16   // waves per workgroup = output positions per iteration
+#endif
+#ifndef AGG_BATCH
+#define AGG_BATCH 16   // ring reads in flight per wave before the adds start
+#endif
 
 template <int VEC> struct VecT;
 template <> struct VecT<1> { typedef float T; };
@@ -132,28 +137,48 @@ k_agg_ring(const float *__restrict__ src, float *__restrict__ dst, const uint32_
         // (b) this wave's output
         if (o < s1) {
             const int neg = (a_cur >> sh_neg) & 0xff, pos = (a_cur >> sh_pos) & 0xff;
+#if defined(AGG_DIAG) && AGG_DIAG == 1
+            const int n = 1;                        // diagnostic build: one term per output
+#else
             const int n = neg + pos + 1;
+#endif
             const int sl = (o - neg) & rmask;
             const int n1 = min(n, R - sl);          // terms before the ring wraps
             vec_t acc = {};
+            // Reads are issued in batches of AGG_BATCH before the (ordered, dependent) adds consume them:
+            // the span is a serial chain, so what matters is how few LDS round trips it is cut into.
             const float *q = rl + sl * SLOT;
             int i = 0;
-            for (; i + 8 <= n1; i += 8) {
-                vec_t v[8];
+            for (; i + AGG_BATCH <= n1; i += AGG_BATCH) {
+                vec_t v[AGG_BATCH];
 #pragma unroll
-                for (int u = 0; u < 8; u++) v[u] = ring_read<vec_t>(q + (i + u) * SLOT);
+                for (int u = 0; u < AGG_BATCH; u++) v[u] = ring_read<vec_t>(q + (i + u) * SLOT);
 #pragma unroll
-                for (int u = 0; u < 8; u++) acc += v[u];
+                for (int u = 0; u < AGG_BATCH; u++) acc += v[u];
+            }
+            for (; i + 4 <= n1; i += 4) {
+                vec_t v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[u] = ring_read<vec_t>(q + (i + u) * SLOT);
+#pragma unroll
+                for (int u = 0; u < 4; u++) acc += v[u];
             }
             for (; i < n1; i++) acc += ring_read<vec_t>(q + i * SLOT);
             const int n2 = n - n1;                  // terms after the wrap, from slot 0
             i = 0;
-            for (; i + 8 <= n2; i += 8) {
-                vec_t v[8];
+            for (; i + AGG_BATCH <= n2; i += AGG_BATCH) {
+                vec_t v[AGG_BATCH];
 #pragma unroll
-                for (int u = 0; u < 8; u++) v[u] = ring_read<vec_t>(rl + (i + u) * SLOT);
+                for (int u = 0; u < AGG_BATCH; u++) v[u] = ring_read<vec_t>(rl + (i + u) * SLOT);
 #pragma unroll
-                for (int u = 0; u < 8; u++) acc += v[u];
+                for (int u = 0; u < AGG_BATCH; u++) acc += v[u];
+            }
+            for (; i + 4 <= n2; i += 4) {
+                vec_t v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[u] = ring_read<vec_t>(rl + (i + u) * SLOT);
+#pragma unroll
+                for (int u = 0; u < 4; u++) acc += v[u];
             }
             for (; i < n2; i++) acc += ring_read<vec_t>(rl + i * SLOT);
             if (DIV) acc = acc / (float)c_cur;

@@ -282,13 +282,14 @@ int enqueue_match(adc_handle *h, const uint8_t *d_l, const uint8_t *d_r, float *
 
     // ScanlineOptimizer::Optimize pass order and ping-pong (ADC/scanline_optimizer.cu:380-447)
     mark(ADC_STAGE_SCAN);
-    launch_scanline_pass(h->vol_b, h->vol_a, pl, g, h->sp, 0, 1, s);
-    launch_scanline_pass(h->vol_a, h->vol_b, pl, g, h->sp, 0, 0, s);
-    launch_scanline_pass(h->vol_b, h->vol_a, pl, g, h->sp, 1, 1, s);
-    launch_scanline_pass(h->vol_a, h->vol_b, pl, g, h->sp, 1, 0, s);
+    launch_scanline_pass(h->vol_b, h->vol_a, pl, g, h->sp, 0, 1, nullptr, s);
+    launch_scanline_pass(h->vol_a, h->vol_b, pl, g, h->sp, 0, 0, nullptr, s);
+    launch_scanline_pass(h->vol_b, h->vol_a, pl, g, h->sp, 1, 1, nullptr, s);
+    // the last pass also produces the left-view WTA map while each pixel's final costs are in registers
+    launch_scanline_pass(h->vol_a, h->vol_b, pl, g, h->sp, 1, 0, h->disp_a, s);
 
     mark(ADC_STAGE_WTA);
-    launch_wta(h->vol_b, h->disp_a, h->disp_r, g, s);
+    launch_wta_right(h->vol_b, h->disp_r, g, s);
     snap(h->snap_wta_l, h->disp_a, npx * sizeof(float));
 
     // MultiStepRefiner::Refine (ADC/multistep_refiner.cu:283-371)

@@ -57,11 +57,12 @@ void launch_aggregate_pass(const float *src, float *dst, const uint32_t *arms, c
 // (d1,d2) reach tso.
 struct ScanParams { float P1[3]; float P2[3]; };
 void launch_scan_records(const Planes &p, const Geom &g, hipStream_t s);
+// disp_wta != nullptr: also write the left-view WTA disparity of every pixel (last pass only).
 void launch_scanline_pass(const float *src, float *dst, const Planes &p, const Geom &g,
-                          const ScanParams &sp, int vertical, int forward, hipStream_t s);
+                          const ScanParams &sp, int vertical, int forward, float *disp_wta, hipStream_t s);
 
 // --- adc_wta.hip -------------------------------------------------------------------------------
-void launch_wta(const float *cost, float *disp_l, float *disp_r, const Geom &g, hipStream_t s);
+void launch_wta_right(const float *cost, float *disp_r, const Geom &g, hipStream_t s);
 
 // --- adc_refine.hip ----------------------------------------------------------------------------
 struct RefineBufs {

@@ -20,6 +20,8 @@
 // by LDS-DMA into a per-wave ring RS pixels ahead of their use, with counted vmcnt waits.
 #include "adc_common.h"
 
+#include <type_traits>
+
 namespace adc {
 
 // ---- colour-step records ----------------------------------------------------------------------------
@@ -152,25 +154,44 @@ __device__ __forceinline__ void lds_read_vec(uint32_t byte_off, float (&v)[NV]) 
     }
 }
 
-template <int NV> struct ScanCfg {
+template <int NV, bool WTA> struct ScanCfg {
     static constexpr int DATA_B = 256 * NV;                         // one pixel's cost vector
     static constexpr int FLAG_B = ((8 * NV + 4 + 15) / 16) * 16;    // its colour-step record, padded to 16 B
     static constexpr int SLOT_B = DATA_B + FLAG_B;
     static constexpr int NDMA = NV >= 4 ? NV / 4 : NV;              // LDS-DMA instructions per cost vector
-    static constexpr int NST = NV >= 4 ? NV / 4 : 1;                // store instructions per cost vector
-    static constexpr int RS = NV <= 4 ? 16 : (NV == 8 ? 8 : 4);     // ring slots per wave (~17 KB)
+    static constexpr int NST = (NV >= 4 ? NV / 4 : 1) + (WTA ? 1 : 0);  // store instructions per path pixel
+    static constexpr int OPS = NDMA + 1 + NST;                      // vector-memory operations per path pixel
+    static constexpr int RS_MEM = NV <= 4 ? 16 : (NV == 8 ? 8 : 4); // ring slots per wave that fit ~17 KB
+    static constexpr int RS_CNT = 63 / OPS + 2;                     // ... and that keep the counted wait within 6 bits
+    static constexpr int RS = RS_MEM < RS_CNT ? RS_MEM : RS_CNT;
     // operations younger than the fill of step s+1 at the point step s waits for it (see the loop)
-    static constexpr int WAITN = (RS - 2) * (NDMA + 1 + NST);
-    static_assert(WAITN <= 63, "vmcnt is a 6-bit counter");
+    static constexpr int WAITN = (RS - 2) * OPS;
+    static_assert(WAITN <= 63 && RS >= 3, "vmcnt is a 6-bit counter");
 };
+
+__device__ __forceinline__ int wave_min_i32(int v) {
+    auto d = [](int old, int src, auto ctrl) {
+        return __builtin_amdgcn_update_dpp(old, src, decltype(ctrl)::value, 0xf, 0xf, false);
+    };
+    v = min(v, d(v, v, std::integral_constant<int, 0x111>()));
+    v = min(v, d(v, v, std::integral_constant<int, 0x112>()));
+    v = min(v, d(v, v, std::integral_constant<int, 0x114>()));
+    v = min(v, d(v, v, std::integral_constant<int, 0x118>()));
+    v = min(v, d(v, v, std::integral_constant<int, 0x142>()));
+    v = min(v, d(v, v, std::integral_constant<int, 0x143>()));
+    return __builtin_amdgcn_readlane(v, 63);
+}
 
 // VERT = 0: wave walks row `line` along x; VERT = 1: walks column `line` along y.
 // FULL: Dp == D == 64*NV, every lane owns NV real disparities (no masking anywhere).
-template <int NV, int VERT, bool FULL>
+// WTA: this is the last pass; while a pixel's final costs are still in registers, also write its
+//      left-view winner-take-all disparity with the sub-pixel fit (ComputeDisparityCuda,
+//      ADC/ADCensusStereo.cu:200-267): first strict minimum over d, invalid (+inf) at either end of the range.
+template <int NV, int VERT, bool FULL, bool WTA>
 __global__ void __launch_bounds__(256)
 k_scanline(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ rec,
-           int W, int H, int D, int Dp, int forward, ScanParams sp) {
-    typedef ScanCfg<NV> C;
+           float *__restrict__ disp, int W, int H, int dmin, int D, int Dp, int forward, ScanParams sp) {
+    typedef ScanCfg<NV, WTA> C;
     extern __shared__ __align__(16) uint8_t lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -251,6 +272,28 @@ k_scanline(const float *__restrict__ src, float *__restrict__ dst, const uint32_
 #pragma unroll
     for (int j = 1; j < NV; j++) lmin = fminf(lmin, Lp[j]);
     float minLp = wave_min(lmin);
+    // c[] = this pixel's final costs (Large_Float past D), cmin = their minimum
+    auto write_wta = [&](const float (&c)[NV], float cmin, ptrdiff_t pixel) {
+        int kk = 0x7fffffff;
+#pragma unroll
+        for (int j = NV - 1; j >= 0; j--) kk = (c[j] == cmin) ? k0 + j : kk;   // first disparity of this lane at the minimum
+        const int best = wave_min_i32(kk);                                      // first over the wave
+        float out = __int_as_float(0x7f800000);                                 // Invalid_Float
+        if (best > 0 && best < D - 1 && cmin < ADC_LARGE_F) {
+            const int l1 = (best - 1) / NV, e1 = (best - 1) - l1 * NV;
+            const int l2 = (best + 1) / NV, e2 = (best + 1) - l2 * NV;
+            float s1 = c[0], s2 = c[0];
+#pragma unroll
+            for (int j = 1; j < NV; j++) { s1 = (e1 == j) ? c[j] : s1; s2 = (e2 == j) ? c[j] : s2; }
+            const float c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s1), l1));
+            const float c2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s2), l2));
+            const float fb = (float)(best + dmin);
+            const float denom = c1 + c2 - 2 * cmin;
+            out = (denom != 0.0f) ? fb + (c1 - c2) / (denom * 2.0f) : fb;
+        }
+        if (lane == 0) disp[pixel] = out;
+    };
+    if (WTA) write_wta(Lp, minLp, pix0);
     if (LEN < 2) return;
 
     // ---- prologue: fills of path pixels 1 .. RS-1, all landed, pixel 1 in registers
@@ -307,6 +350,7 @@ k_scanline(const float *__restrict__ src, float *__restrict__ dst, const uint32_
 #pragma unroll
         for (int j = 0; j < NV; j++) Lp[j] = nw[j];
         minLp = wave_min(lm);
+        if (WTA) write_wta(Lp, minLp, pix0 + (ptrdiff_t)s * pstep);
         // (E)
 #pragma unroll
         for (int j = 0; j < NV; j++) cur[j] = nxt[j];
@@ -315,10 +359,10 @@ k_scanline(const float *__restrict__ src, float *__restrict__ dst, const uint32_
     }
 }
 
-template <int NV>
-static void launch_nv(const float *src, float *dst, const Planes &p, const Geom &g, const ScanParams &sp,
+template <int NV, bool WTA>
+static void launch_nv(const float *src, float *dst, float *disp, const Planes &p, const Geom &g, const ScanParams &sp,
                       int vertical, int forward, hipStream_t s) {
-    typedef ScanCfg<NV> C;
+    typedef ScanCfg<NV, WTA> C;
     const int nlines = vertical ? g.W : g.H;
     dim3 grid((nlines + 3) / 4), block(256);
     const size_t lds = (size_t)4 * C::RS * C::SLOT_B;
@@ -327,30 +371,31 @@ static void launch_nv(const float *src, float *dst, const Planes &p, const Geom 
     static bool attr_set = false;
     if (!attr_set) {
         const int cap = 96 * 1024;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scanline<NV, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scanline<NV, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scanline<NV, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scanline<NV, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scanline<NV, 0, true, WTA>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scanline<NV, 1, true, WTA>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scanline<NV, 0, false, WTA>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scanline<NV, 1, false, WTA>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         attr_set = true;
     }
-    if (vertical) {
-        if (full) k_scanline<NV, 1, true><<<grid, block, lds, s>>>(src, dst, rec, g.W, g.H, g.D, g.Dp, forward, sp);
-        else k_scanline<NV, 1, false><<<grid, block, lds, s>>>(src, dst, rec, g.W, g.H, g.D, g.Dp, forward, sp);
-    } else {
-        if (full) k_scanline<NV, 0, true><<<grid, block, lds, s>>>(src, dst, rec, g.W, g.H, g.D, g.Dp, forward, sp);
-        else k_scanline<NV, 0, false><<<grid, block, lds, s>>>(src, dst, rec, g.W, g.H, g.D, g.Dp, forward, sp);
-    }
+#define ADC_SCAN(V, F) k_scanline<NV, V, F, WTA><<<grid, block, lds, s>>>(src, dst, rec, disp, g.W, g.H, g.dmin, g.D, g.Dp, forward, sp)
+    if (vertical) { if (full) ADC_SCAN(1, true); else ADC_SCAN(1, false); }
+    else { if (full) ADC_SCAN(0, true); else ADC_SCAN(0, false); }
+#undef ADC_SCAN
 }
 
 void launch_scanline_pass(const float *src, float *dst, const Planes &p, const Geom &g,
-                          const ScanParams &sp, int vertical, int forward, hipStream_t s) {
+                          const ScanParams &sp, int vertical, int forward, float *disp_wta, hipStream_t s) {
+#define ADC_NV(N)                                                                    \
+    if (disp_wta) launch_nv<N, true>(src, dst, disp_wta, p, g, sp, vertical, forward, s); \
+    else launch_nv<N, false>(src, dst, nullptr, p, g, sp, vertical, forward, s)
     switch (g.NV) {
-        case 1: launch_nv<1>(src, dst, p, g, sp, vertical, forward, s); break;
-        case 2: launch_nv<2>(src, dst, p, g, sp, vertical, forward, s); break;
-        case 4: launch_nv<4>(src, dst, p, g, sp, vertical, forward, s); break;
-        case 8: launch_nv<8>(src, dst, p, g, sp, vertical, forward, s); break;
-        default: launch_nv<16>(src, dst, p, g, sp, vertical, forward, s); break;
+        case 1: ADC_NV(1); break;
+        case 2: ADC_NV(2); break;
+        case 4: ADC_NV(4); break;
+        case 8: ADC_NV(8); break;
+        default: ADC_NV(16); break;
     }
+#undef ADC_NV
 }
 
 }  // namespace adc
