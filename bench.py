@@ -76,26 +76,9 @@ def main():
     def step(i):
         h.match_device(d_l[i & 1].data_ptr(), d_r[i & 1].data_ptr(), d_out.data_ptr(), stream)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    batch = importlib.import_module("stereo-matching_amd.batch")
+    elapsed = batch.timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize,
+                                dist if world > 1 else None, dev)
 
     valid_fraction = float(torch.isfinite(d_out).float().mean().item())
 
@@ -116,11 +99,10 @@ def main():
     achieved = algo_bytes / (agg_launch_ms * 1e-3) / 1e9
 
     if rank == 0:
-        units = world * args.steps * (W * H * D * 1e-6)    # Mpix*disp over the whole job
         ms_per_frame = elapsed / args.steps * 1e3
         out = {
             "metric": "Mpix*disp/s",
-            "value": units / elapsed,
+            "value": batch.throughput(world, args.steps, W, H, D, elapsed),
             "unit": "Mpix*disp/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -145,15 +127,17 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as orc          # reported baseline only; never on the measured path
-            hs = max(32, H // 2)                       # bounded sample: the upper half of one frame
-            Ls = np.ascontiguousarray(pairs[0][0][:hs])
-            Rs = np.ascontiguousarray(pairs[0][1][:hs])
+            # bounded sample of the same workload: whole frames until ~10 s of CPU time (1..4 frames)
             t1 = time.perf_counter()
-            orc.match(Ls, Rs, orc.default_option(max_disparity=D))
+            n_cpu = 0
+            while n_cpu < 4 and (n_cpu == 0 or time.perf_counter() - t1 < 10.0):
+                orc.match(pairs[n_cpu & 1][0], pairs[n_cpu & 1][1], orc.default_option(max_disparity=D))
+                n_cpu += 1
             cpu_s = time.perf_counter() - t1
-            out["cpu_baseline"] = {"value": W * hs * D * 1e-6 / cpu_s, "unit": "Mpix*disp/s",
+            out["cpu_baseline"] = {"value": n_cpu * W * H * D * 1e-6 / cpu_s, "unit": "Mpix*disp/s",
                                    "cores": orc.num_threads(), "kind": "port",
-                                   "sample": "rows 0..%d of one %dx%dx%d pair (%.1f s)" % (hs - 1, W, H, D, cpu_s)}
+                                   "sample": "%d whole %dx%dx%d pair(s), %.1f s of OpenMP CPU time on %d threads"
+                                             % (n_cpu, W, H, D, cpu_s, orc.num_threads())}
         print(json.dumps(out), flush=True)
     h.close()
     if world > 1:

@@ -71,3 +71,11 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")) or f == "Makefile":
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle" not in txt.replace("the CPU oracle", "").lower() or f == "Makefile", os.path.join(dp, f)
+
+
+def test_cpp_shim_error_paths(pkg):
+    """include/ADCensusStereo.hpp compiled as plain C++ against the C-ABI: the reference's `return false` paths."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(pkg.__file__), "bin", "shim_check")
+    assert os.path.exists(exe), "build bin/shim_check first (make -C stereo-matching_amd)"
+    assert subprocess.run([exe, "--errors"], capture_output=True).returncode == 0

@@ -191,6 +191,19 @@ def test_match_device_and_batch(pkg, orc, synth):
         assert same(d, orc.match(l, r, orc.default_option(max_disparity=32))[0])
 
 
+def test_cpp_shim_program(pkg, orc, synth, tmp_path):
+    """The reference caller's C++ sequence (Initialize, Match, Match(null), Match) through ADCensusStereo.hpp."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(pkg.__file__), "bin", "shim_check")
+    assert os.path.exists(exe), "build bin/shim_check first (make -C stereo-matching_amd)"
+    L, R, _ = synth.pair(61, 180, 100, 48)
+    L.tofile(tmp_path / "l.raw")
+    R.tofile(tmp_path / "r.raw")
+    subprocess.check_call([exe, "180", "100", "2", "50", str(tmp_path / "l.raw"), str(tmp_path / "r.raw"), str(tmp_path / "o.raw")])
+    got = np.fromfile(tmp_path / "o.raw", dtype=np.float32).reshape(100, 180)
+    assert same(got, orc.match(L, R, orc.default_option(min_disparity=2, max_disparity=50))[0])
+
+
 def test_full_resolution_2021_scene(pkg, orc):
     """1920x1080, 256 disparities: the final map against the committed oracle output, and the
     refinement chain re-run by the oracle on the GPU's own WTA maps."""
