@@ -98,6 +98,15 @@ def main():
     algo_bytes = 8.0 * W * H * D                       # one pass: read 4 B + write 4 B per pixel*disparity
     achieved = algo_bytes / (agg_launch_ms * 1e-3) / 1e9
 
+    # HBM bytes per launch of that kernel as measured by the PMC passes committed under profiles/
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if tj["workload"] == {"width": W, "height": H, "disparities": D}:
+            traffic = tj["k_agg_ring"]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+
     if rank == 0:
         ms_per_frame = elapsed / args.steps * 1e3
         out = {
@@ -122,7 +131,7 @@ def main():
             "valid_fraction": valid_fraction,
             "roofline": {"bound": "hbm", "kernel": "k_agg_ring (one cross-aggregation pass)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": agg_launch_ms},
         }
         if world == 1 and not args.no_cpu_baseline:
