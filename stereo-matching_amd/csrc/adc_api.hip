@@ -45,6 +45,7 @@ struct adc_handle {
     // tables
     float *lut_ad = nullptr, *lut_cen = nullptr;
     double *ray_dy = nullptr, *ray_dx = nullptr;
+    uint32_t *ray_off = nullptr;   // rounded (dy, dx) offsets, or null when some entry sits too close to a rounding tie
     int ray_len = 0;
     ScanParams sp{};
     // disparity maps and masks
@@ -219,6 +220,20 @@ int do_initialize(adc_handle *h, int32_t W, int32_t H, const adc_option *opt) {
         if ((rc = dev_alloc(h, &h->ray_dx, dx.size()))) return rc;
         HIPCHK(h, hipMemcpy(h->ray_dy, dy.data(), dy.size() * sizeof(double), hipMemcpyHostToDevice));
         HIPCHK(h, hipMemcpy(h->ray_dx, dx.data(), dx.size() * sizeof(double), hipMemcpyHostToDevice));
+        // round((double)y + v) == y + round(v) for every integer |y| < 2^16 unless v is within a few ulps
+        // (of 2^17) of a half-integer; with a margin of 1e-6 the integer offsets can replace the doubles.
+        h->ray_off = nullptr;
+        bool int_ok = h->ray_len <= 32000 && !std::getenv("ADC_INTERP_DOUBLE");
+        std::vector<uint32_t> off(dy.size());
+        for (size_t i = 0; int_ok && i < dy.size(); i++) {
+            const double ry = std::round(dy[i]), rx = std::round(dx[i]);
+            if (std::fabs(std::fabs(dy[i] - ry) - 0.5) < 1e-6 || std::fabs(std::fabs(dx[i] - rx) - 0.5) < 1e-6) int_ok = false;
+            off[i] = (uint32_t)(uint16_t)(int16_t)ry << 16 | (uint32_t)(uint16_t)(int16_t)rx;
+        }
+        if (int_ok) {
+            if ((rc = dev_alloc(h, &h->ray_off, off.size()))) return rc;
+            HIPCHK(h, hipMemcpy(h->ray_off, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
     }
     // penalty table (ADC/scanline_optimizer.cu:97-109)
     h->sp.P1[0] = opt->so_p1; h->sp.P1[1] = opt->so_p1 / 4; h->sp.P1[2] = opt->so_p1 / 10;
@@ -316,7 +331,7 @@ int enqueue_match(adc_handle *h, const uint8_t *d_l, const uint8_t *d_r, float *
     snap(h->snap_voting, cur, npx * sizeof(float));
     if (o.do_filling) {
         launch_interpolate(cur, h->occ, h->mis, h->list_mis, h->list_occ, h->counters, h->newval, pl.pix_l,
-                           h->ray_dy, h->ray_dx, g, h->ray_len, s);
+                           h->ray_dy, h->ray_dx, h->ray_off, g, h->ray_len, s);
     }
     snap(h->snap_interp, cur, npx * sizeof(float));
     if (o.do_discontinuity_adjustment) {

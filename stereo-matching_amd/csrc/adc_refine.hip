@@ -15,6 +15,19 @@ namespace adc {
 // lround() of the reference: round half away from zero.
 __device__ __forceinline__ int lround_f(float v) { return (int)roundf(v); }
 
+// Append `value` to a list for every lane with `flag` set: one atomic per wavefront reserves the
+// slots, each flagged lane takes the slot given by its rank among the flagged lanes.
+__device__ __forceinline__ void wave_append(bool flag, uint32_t *__restrict__ list, uint32_t *counter, uint32_t value) {
+    const unsigned long long m = __ballot(flag);
+    if (m == 0) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = __shfl(base, leader, 64);
+    if (flag) list[base + __popcll(m & ((1ull << lane) - 1ull))] = value;
+}
+
 // ---- outlier detection (OutlierDetectionCuda, ADC/multistep_refiner.cu:70-156) --------------------
 __global__ void __launch_bounds__(256)
 k_outlier(const float *__restrict__ dl, const float *__restrict__ dr, float *__restrict__ out,
@@ -22,12 +35,14 @@ k_outlier(const float *__restrict__ dl, const float *__restrict__ dr, float *__r
           uint32_t *__restrict__ list_occ, uint32_t *__restrict__ counters, int W, int H, float thres) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= W || y >= H) return;
-    const size_t i = (size_t)y * W + x;
+    if (y >= H) return;               // wave-uniform
+    const bool in = x < W;
+    const size_t i = (size_t)y * W + (in ? x : 0);
     const float d = dl[i];
     float o = d;
     bool is_occ = false, is_mis = false;
-    if (d < 0) {                      // MinDispMismatch = 0 (ADC/config.h:4)
+    if (!in) {
+    } else if (d < 0) {               // MinDispMismatch = 0 (ADC/config.h:4)
         o = ADC_INF; is_mis = true;
     } else if (d == ADC_INF) {
         is_mis = true;
@@ -49,11 +64,13 @@ k_outlier(const float *__restrict__ dl, const float *__restrict__ dr, float *__r
             o = ADC_INF; is_mis = true;
         }
     }
-    out[i] = o;
-    occ[i] = is_occ;
-    mis[i] = is_mis;
-    if (is_mis) list_mis[atomicAdd(&counters[0], 1u)] = (uint32_t)i;
-    if (is_occ) list_occ[atomicAdd(&counters[1], 1u)] = (uint32_t)i;
+    if (in) {
+        out[i] = o;
+        occ[i] = is_occ;
+        mis[i] = is_mis;
+    }
+    wave_append(is_mis, list_mis, &counters[0], (uint32_t)i);
+    wave_append(is_occ, list_occ, &counters[1], (uint32_t)i);
 }
 
 void launch_outlier(const float *dl, const float *dr, float *out, uint8_t *occ, uint8_t *mis,
@@ -71,8 +88,11 @@ void launch_clear_masks(uint8_t *occ, uint8_t *mis, uint32_t *counters, size_t n
 }
 
 // ---- iterative region voting (RegionVotingCuda + DeleteFilledPixel, ADC/multistep_refiner.cu:376-449)
-// One wavefront (= one 64-thread workgroup slot) per listed pixel: the disparity histogram of the
-// cross support region is built in LDS, lanes striding over each row's horizontal span.
+// One wavefront (= one 64-thread workgroup) per listed pixel: the disparity histogram of the cross
+// support region is built in LDS. The arms of up to 64 region rows are fetched with one load (lane <->
+// row); each row's horizontal span is then read with lanes along the row, VOTE_ROWS rows per batch so
+// that their loads are in flight together instead of one dependent round trip per row.
+#define VOTE_ROWS 8
 __global__ void __launch_bounds__(64)
 k_vote(const float *__restrict__ disp, const uint8_t *__restrict__ mask, const uint32_t *__restrict__ list,
        const uint32_t *__restrict__ count, float *__restrict__ newval, const uint32_t *__restrict__ arms,
@@ -88,15 +108,45 @@ k_vote(const float *__restrict__ disp, const uint8_t *__restrict__ mask, const u
             __syncthreads();
             const uint32_t a = arms[p];
             const int top = (a >> 16) & 0xff, bot = a >> 24;
-            for (int t = -top; t <= bot; t++) {
-                const size_t q = (size_t)p + (ptrdiff_t)t * W;
-                const uint32_t a2 = arms[q];
-                const int l2 = a2 & 0xff, r2 = (a2 >> 8) & 0xff;
-                for (int s = lane - l2; s <= r2; s += 64) {
-                    const float dd = disp[q + s];
-                    if (dd != ADC_INF) {
-                        const int bin = lround_f(dd) - dmin;
-                        if (bin >= 0 && bin < D) atomicAdd(&hist[bin], 1);
+            const int nrows = top + bot + 1;
+            for (int r0 = 0; r0 < nrows; r0 += 64) {
+                const int nr = min(64, nrows - r0);
+                const size_t qrow = (size_t)p + (ptrdiff_t)(r0 - top) * W;    // first row of this chunk
+                uint32_t arow = 0;
+                if (lane < nr) arow = arms[qrow + (size_t)lane * W];
+                for (int t0 = 0; t0 < nr; t0 += VOTE_ROWS) {
+                    float da[VOTE_ROWS], db[VOTE_ROWS];
+                    bool any_b = false;
+#pragma unroll
+                    for (int u = 0; u < VOTE_ROWS; u++) {
+                        da[u] = ADC_INF;
+                        db[u] = ADC_INF;
+                        if (t0 + u < nr) {                                   // uniform
+                            const uint32_t a2 = __builtin_amdgcn_readlane(arow, t0 + u);
+                            const int l2 = a2 & 0xff, r2 = (a2 >> 8) & 0xff;
+                            const float *row = disp + qrow + (size_t)(t0 + u) * W - l2;
+                            if (lane <= l2 + r2) da[u] = row[lane];
+                            if (l2 + r2 >= 64) {                             // uniform, spans longer than a wave
+                                any_b = true;
+                                if (lane + 64 <= l2 + r2) db[u] = row[lane + 64];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < VOTE_ROWS; u++) {
+                        if (da[u] != ADC_INF) {
+                            const int bin = lround_f(da[u]) - dmin;
+                            if (bin >= 0 && bin < D) atomicAdd(&hist[bin], 1);
+                        }
+                    }
+                    if (any_b) {
+#pragma unroll
+                        for (int u = 0; u < VOTE_ROWS; u++) {
+                            if (db[u] != ADC_INF) {
+                                const int bin = lround_f(db[u]) - dmin;
+                                if (bin >= 0 && bin < D) atomicAdd(&hist[bin], 1);
+                            }
+                        }
                     }
                 }
             }
@@ -148,48 +198,116 @@ void launch_region_voting_pass(float *disp, uint8_t *mask, const uint32_t *list,
 
 // ---- proper interpolation (FillDisp, ADC/multistep_refiner.cu:543-633) ------------------------------
 // ray_dy / ray_dx hold the host-computed products m*sin(ang_s), m*cos(ang_s) (double) for the 16
-// directions, so the device only adds and rounds.
+// directions, so the device only adds and rounds. 16 lanes share one listed pixel, one ray each, and
+// walk their rays INTERP_STEPS samples at a time (independent loads); the reference's sequential
+// scan over the directions (first smallest colour difference wins, ADC/multistep_refiner.cu:596-622)
+// becomes a lexicographic (difference, direction) minimum over the 16 lanes.
+// When every table entry is far from a rounding tie, round(y + m*sin) == y + round(m*sin) for every
+// integer y, and the host hands over the rounded offsets instead (ray_off: int16 dy << 16 | int16 dx,
+// staged in LDS when LDS_TAB); otherwise the double tables are used as they are.
+#define INTERP_STEPS 4
+template <bool INT_TAB, bool LDS_TAB>
 __global__ void __launch_bounds__(256)
 k_interp(const float *__restrict__ disp, const uint8_t *__restrict__ occ, const uint8_t *__restrict__ mis,
          const uint32_t *__restrict__ list_mis, const uint32_t *__restrict__ list_occ,
          const uint32_t *__restrict__ counters, float *__restrict__ newval, const uint32_t *__restrict__ pix,
-         const double *__restrict__ ray_dy, const double *__restrict__ ray_dx, int W, int H, int maxlen,
-         size_t npx) {
+         const double *__restrict__ ray_dy, const double *__restrict__ ray_dx, const uint32_t *__restrict__ ray_off,
+         int W, int H, int maxlen, size_t npx) {
+    extern __shared__ uint32_t s_off[];              // LDS_TAB: 16 x maxlen offsets
     const uint32_t n_mis = counters[0], n_occ = counters[1];
     const uint32_t n = n_mis + n_occ;
-    for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+    const int s = threadIdx.x & 15;                  // this lane's direction
+    const double *dy = ray_dy + (size_t)s * maxlen;
+    const double *dx = ray_dx + (size_t)s * maxlen;
+    const uint32_t *off = ray_off + (size_t)s * maxlen;
+    if (LDS_TAB) {
+        for (int i = threadIdx.x; i < 16 * maxlen; i += 256) s_off[i] = ray_off[i];
+        __syncthreads();
+        off = s_off + s * maxlen;
+    }
+    const uint32_t per_block = 256 / 16;
+    for (uint32_t e0 = blockIdx.x * per_block; e0 < n; e0 += gridDim.x * per_block) {
+        const uint32_t e = e0 + (threadIdx.x >> 4);
+        const bool live = e < n;
         const bool from_mis = e < n_mis;
-        const uint32_t p = from_mis ? list_mis[e] : list_occ[e - n_mis];
-        const size_t slot = from_mis ? (size_t)e : npx + (e - n_mis);
-        float result = ADC_INF;
-        const bool m = mis[p] != 0, o = occ[p] != 0;
-        if (m || o) {
-            const int y = (int)(p / (uint32_t)W), x = (int)(p - (uint32_t)y * W);
-            const uint32_t c0 = pix[p];
-            int best_diff = 9999;
-            float best_d = 0.0f, min_d = ADC_LARGE_F;
-            int num = 0;
-            for (int s = 0; s < 16; s++) {
-                const double *dy = ray_dy + (size_t)s * maxlen;
-                const double *dx = ray_dx + (size_t)s * maxlen;
-                for (int mm = 1; mm < maxlen; mm++) {
-                    const int yy = (int)round((double)y + dy[mm]);
-                    const int xx = (int)round((double)x + dx[mm]);
-                    if (yy < 0 || yy >= H || xx < 0 || xx >= W) break;
-                    const size_t q = (size_t)yy * W + xx;
-                    const float d = disp[q];
-                    if (d != ADC_INF) {
-                        num++;
-                        const int diff = (int)__builtin_amdgcn_sad_u8(c0, pix[q], 0u);
-                        if (best_diff > diff) { best_diff = diff; best_d = d; }
-                        min_d = d < min_d ? d : min_d;
-                        break;
+        uint32_t p = 0;
+        bool m = false, o = false;
+        if (live) {
+            p = from_mis ? list_mis[e] : list_occ[e - n_mis];
+            m = mis[p] != 0;
+            o = occ[p] != 0;
+        }
+        const int y = (int)(p / (uint32_t)W), x = (int)(p - (uint32_t)y * W);
+        bool found = false;
+        float fd = 0.0f;
+        size_t fq = 0;
+        bool walking = live && (m || o);
+        for (int mm = 1; mm < maxlen && __any(walking); mm += INTERP_STEPS) {
+            float d[INTERP_STEPS];
+            size_t q[INTERP_STEPS];
+            bool in[INTERP_STEPS];
+            bool ok = walking;
+#pragma unroll
+            for (int u = 0; u < INTERP_STEPS; u++) {
+                d[u] = ADC_INF;
+                q[u] = 0;
+                in[u] = false;
+                if (ok && mm + u < maxlen) {
+                    int yy, xx;
+                    if (INT_TAB) {
+                        const uint32_t o2 = off[mm + u];
+                        yy = y + ((int)o2 >> 16);
+                        xx = x + (int)(short)(o2 & 0xffffu);
+                    } else {
+                        yy = (int)round((double)y + dy[mm + u]);
+                        xx = (int)round((double)x + dx[mm + u]);
+                    }
+                    if (yy < 0 || yy >= H || xx < 0 || xx >= W) {
+                        ok = false;                  // the ray leaves the image: nothing beyond counts
+                    } else {
+                        in[u] = true;
+                        q[u] = (size_t)yy * W + xx;
+                        d[u] = disp[q[u]];
+                    }
+                } else {
+                    ok = false;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < INTERP_STEPS; u++) {
+                if (walking) {
+                    if (!in[u]) {
+                        walking = false;             // left the image or ran out of samples
+                    } else if (d[u] != ADC_INF) {
+                        found = true;
+                        fd = d[u];
+                        fq = q[u];
+                        walking = false;
                     }
                 }
             }
-            if (num) result = m ? best_d : min_d;
         }
-        newval[slot] = result;
+        // combine the 16 directions of a pixel
+        int key = 0x7fffffff;                        // (colour difference << 4) | direction; lower wins
+        float mind = ADC_LARGE_F;
+        if (found) {
+            const int diff = (int)__builtin_amdgcn_sad_u8(pix[p], pix[fq], 0u);
+            key = (diff << 4) | s;
+            mind = fd;
+        }
+        int bkey = key;
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) {
+            bkey = min(bkey, __shfl_xor(bkey, off, 16));
+            mind = fminf(mind, __shfl_xor(mind, off, 16));
+        }
+        // disparity collected by the winning direction
+        const float best_d = __shfl(fd, (int)((threadIdx.x & 48) | (bkey & 15)), 64);
+        if (live && s == 0) {
+            float result = ADC_INF;
+            if ((m || o) && bkey != 0x7fffffff) result = m ? best_d : mind;
+            newval[from_mis ? (size_t)e : npx + (e - n_mis)] = result;
+        }
     }
 }
 
@@ -209,10 +327,15 @@ k_apply_interp(float *__restrict__ disp, const uint32_t *__restrict__ list_mis, 
 void launch_interpolate(float *disp, const uint8_t *occ, const uint8_t *mis,
                         const uint32_t *list_mis, const uint32_t *list_occ, const uint32_t *counters,
                         float *newval, const uint32_t *pix_l, const double *ray_dy, const double *ray_dx,
-                        const Geom &g, int maxlen, hipStream_t s) {
+                        const uint32_t *ray_off, const Geom &g, int maxlen, hipStream_t s) {
     const size_t npx = (size_t)g.W * g.H;
-    k_interp<<<dim3(2048), dim3(256), 0, s>>>(disp, occ, mis, list_mis, list_occ, counters, newval, pix_l,
-                                             ray_dy, ray_dx, g.W, g.H, maxlen, npx);
+    const size_t tab = (size_t)16 * maxlen * sizeof(uint32_t);
+#define ADC_INTERP(I, L, LDS) k_interp<I, L><<<dim3(8192), dim3(256), LDS, s>>>( \
+        disp, occ, mis, list_mis, list_occ, counters, newval, pix_l, ray_dy, ray_dx, ray_off, g.W, g.H, maxlen, npx)
+    if (!ray_off) ADC_INTERP(false, false, 0);
+    else if (tab <= 48 * 1024) ADC_INTERP(true, true, tab);
+    else ADC_INTERP(true, false, 0);
+#undef ADC_INTERP
     k_apply_interp<<<dim3(512), dim3(256), 0, s>>>(disp, list_mis, list_occ, counters, newval, npx);
 }
 
