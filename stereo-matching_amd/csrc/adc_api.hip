@@ -167,6 +167,7 @@ int do_initialize(adc_handle *h, int32_t W, int32_t H, const adc_option *opt) {
     {
         const size_t nrec = npx * (size_t)(2 * g.NV + 1);
         A(h->pl.rec_hf, nrec); A(h->pl.rec_hb, nrec); A(h->pl.rec_v, nrec);
+        A(h->pl.rec_rows, (size_t)3 * g.H * scan_row_dwords(g));
     }
     A(h->vol_a, nvol); A(h->vol_b, nvol);
     A(h->lut_ad, 768); A(h->lut_cen, 68);

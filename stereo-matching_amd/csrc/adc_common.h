@@ -32,6 +32,7 @@ struct Planes {
     uint16_t *cnt_h, *cnt_v;
     uint32_t *cnt_h32, *cnt_v32;    // same counts widened to 32 bits (dword scalar loads in the aggregation kernel)
     uint32_t *rec_hf, *rec_hb, *rec_v;  // per-pixel colour-step records of the scanline passes, (2*NV+1) dwords each
+    uint32_t *rec_rows;                 // per-row packed right-image step flags the records are cut from (3 families)
 };
 
 // --- adc_pre.hip -------------------------------------------------------------------------------
@@ -56,6 +57,7 @@ void launch_aggregate_pass(const float *src, float *dst, const uint32_t *arms, c
 // One directional scanline pass (src -> dst). Ptab = {P1[0..2], P2[0..2]} indexed by how many of
 // (d1,d2) reach tso.
 struct ScanParams { float P1[3]; float P2[3]; };
+int scan_row_dwords(const Geom &g);
 void launch_scan_records(const Planes &p, const Geom &g, hipStream_t s);
 // disp_wta != nullptr: also write the left-view WTA disparity of every pixel (last pass only).
 void launch_scanline_pass(const float *src, float *dst, const Planes &p, const Geom &g,

@@ -35,53 +35,95 @@ namespace adc {
 // dword whose bit 0 is the d1 flag. One table per path family: horizontal forward, horizontal
 // backward, vertical (the backward vertical pass reads the record one row further down, because the
 // pair (y, y+1) is stored at y+1).
+//
+// Built in two steps. k_scan_rows packs, per image row and family, the right-image flags into a bit
+// string E indexed by j = (W-2) - xr, clamped to the usable columns (E[j] = flag at column
+// clamp(W-2-j, 1, W-2)): along a pixel's disparities j = (W-2-x+dmin) + k ascends with k, so a record
+// dword is 32 consecutive bits of E (one funnel shift), with the d1 flag in front while j < 0.
 __global__ void __launch_bounds__(256)
-k_scan_records(const uint8_t *__restrict__ step_l, const uint8_t *__restrict__ step_r, uint32_t *__restrict__ rec_hf,
-               uint32_t *__restrict__ rec_hb, uint32_t *__restrict__ rec_v, int W, int H, int dmin, int D, int recw) {
+k_scan_rows(const uint8_t *__restrict__ step_r, uint32_t *__restrict__ erow, int W, int H, int ne) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)H * ne) return;
+    const int y = (int)(gid / ne), jw = (int)(gid - (size_t)y * ne);
+    const uint8_t *rrow = step_r + (size_t)y * W;
+    uint32_t b_hf = 0, b_hb = 0, b_v = 0;
+    if (W >= 3) {
+        for (int b = 0; b < 32; b++) {
+            const int xc = min(max(W - 2 - (jw * 32 + b), 1), W - 2);
+            const uint32_t s0 = rrow[xc], s1 = rrow[xc + 1];
+            b_hf |= (s0 & 1u) << b;          // step between right pixels xc and xc-1
+            b_hb |= (s1 & 1u) << b;          // step between right pixels xc and xc+1
+            b_v |= ((s0 >> 1) & 1u) << b;    // step between rows y and y-1 at column xc
+        }
+    }
+    const size_t fam = (size_t)H * ne;
+    erow[gid] = b_hf;
+    erow[fam + gid] = b_hb;
+    erow[2 * fam + gid] = b_v;
+}
+
+// 32 bits of the string (f1 repeated for j < 0, then E) starting at bit jj
+__device__ __forceinline__ uint32_t rec_bits(const uint32_t *__restrict__ e, int jj, uint32_t f1) {
+    const uint32_t fill = f1 ? 0xffffffffu : 0u;
+    if (jj <= -32) return fill;
+    if (jj < 0) return (e[0] << (-jj)) | (fill >> (32 + jj));
+    const uint32_t lo = e[jj >> 5], hi = e[(jj >> 5) + 1];
+    return __funnelshift_r(lo, hi, jj & 31);
+}
+
+__global__ void __launch_bounds__(256)
+k_scan_records(const uint8_t *__restrict__ step_l, const uint32_t *__restrict__ erow, uint32_t *__restrict__ rec_hf,
+               uint32_t *__restrict__ rec_hb, uint32_t *__restrict__ rec_v, int W, int H, int dmin, int D, int recw, int ne) {
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)W * H * recw;
     if (gid >= total) return;
     const size_t p = gid / recw;
     const int w = (int)(gid - p * recw);
     const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
-    const uint8_t *rrow = step_r + (size_t)y * W;
-    const uint32_t f1_hf = step_l[p] & 1u;
+    const uint32_t sl = step_l[p];
+    const uint32_t f1_hf = sl & 1u;
     const uint32_t f1_hb = (x + 1 < W) ? (step_l[p + 1] & 1u) : 0u;
-    const uint32_t f1_v = (step_l[p] >> 1) & 1u;
+    const uint32_t f1_v = (sl >> 1) & 1u;
     if (w == recw - 1) {
         rec_hf[gid] = f1_hf;
         rec_hb[gid] = f1_hb;
         rec_v[gid] = f1_v;
         return;
     }
-    const bool none = (x - dmin < 1) || (W < 3);   // no disparity of this pixel has 0 < xr < W-1
     uint32_t b_hf = 0, b_hb = 0, b_v = 0;
-    for (int b = 0; b < 32; b++) {
-        const int k = w * 32 + b;
-        if (k >= D) break;
-        const int xe = x - dmin - k;
-        uint32_t e_hf = f1_hf, e_hb = f1_hb, e_v = f1_v;
-        if (!(none || xe >= W - 1)) {
-            const int xc = min(max(xe, 1), W - 2);
-            const uint32_t s0 = rrow[xc], s1 = rrow[xc + 1];
-            e_hf = s0 & 1u;          // step between right pixels xc and xc-1
-            e_hb = s1 & 1u;          // step between right pixels xc and xc+1
-            e_v = (s0 >> 1) & 1u;    // step between rows y and y-1 at column xc
+    const int nb = D - w * 32;                      // disparities this dword covers
+    if (nb > 0) {
+        const bool none = (x - dmin < 1) || (W < 3);   // no disparity of this pixel has 0 < xr < W-1
+        const int jj = none ? -32 : (W - 2 - x + dmin) + w * 32;
+        const size_t fam = (size_t)H * ne;
+        const uint32_t *e = erow + (size_t)y * ne;
+        b_hf = rec_bits(e, jj, f1_hf);
+        b_hb = rec_bits(e + fam, jj, f1_hb);
+        b_v = rec_bits(e + 2 * fam, jj, f1_v);
+        if (nb < 32) {
+            const uint32_t m = (1u << nb) - 1u;
+            b_hf &= m; b_hb &= m; b_v &= m;
         }
-        b_hf |= e_hf << b;
-        b_hb |= e_hb << b;
-        b_v |= e_v << b;
     }
     rec_hf[gid] = b_hf;
     rec_hb[gid] = b_hb;
     rec_v[gid] = b_v;
 }
 
+// dwords per row and family of the packed flag strings: every j a record can reach, plus one dword
+int scan_row_dwords(const Geom &g) {
+    const long long jmax = (long long)g.W - 2 + (g.dmin > 0 ? g.dmin : 0) + g.D + 64;
+    return (int)(jmax / 32) + 2;
+}
+
 void launch_scan_records(const Planes &p, const Geom &g, hipStream_t s) {
     const int recw = 2 * g.NV + 1;
+    const int ne = scan_row_dwords(g);
+    const size_t nrow = (size_t)g.H * ne;
+    k_scan_rows<<<dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, s>>>(p.step_r, p.rec_rows, g.W, g.H, ne);
     const size_t total = (size_t)g.W * g.H * recw;
-    k_scan_records<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(p.step_l, p.step_r, p.rec_hf, p.rec_hb, p.rec_v,
-                                                                             g.W, g.H, g.dmin, g.D, recw);
+    k_scan_records<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(p.step_l, p.rec_rows, p.rec_hf, p.rec_hb, p.rec_v,
+                                                                             g.W, g.H, g.dmin, g.D, recw, ne);
 }
 
 // ---- the pass ----------------------------------------------------------------------------------------

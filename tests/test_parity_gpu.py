@@ -238,3 +238,24 @@ def test_full_resolution_synthetic_bench_pair(pkg, synth):
     assert fnv1a64(disp) == g["hash"]["disp_final"]
     assert fnv1a64(h.get_buffer("disp_right_wta")) == g["hash"]["disp_right_wta"]
     h.close()
+
+
+def test_uhd_512_disparities(pkg, orc, synth):
+    """3840x2160, 512 disparities (two 17 GB volumes resident in HBM; 8 disparities per lane in the
+    scanline kernels): the final map against the oracle run on the same host, and run-to-run determinism.
+    The oracle needs ~70 GB of host memory at this size, so the comparison is skipped on smaller hosts."""
+    import psutil
+    L, R, _ = synth.pair(2026, 3840, 2160, 512)
+    h = pkg.ADCensusStereo(0)
+    assert h.Initialize(3840, 2160, pkg.ADCensusOption(max_disparity=512)), h.last_error()
+    a = h.match(L, R)
+    dr = h.get_buffer("disp_right_wta")
+    b = h.match(L, R)
+    assert same(a, b)
+    assert np.isfinite(a).mean() > 0.9
+    h.close()
+    if psutil.virtual_memory().available < 110 * 2**30:
+        pytest.skip("host too small for the 4K x 512 oracle; determinism checked only")
+    want, taps = orc.match(L, R, orc.default_option(max_disparity=512), want=["disp_right_wta"])
+    assert same(dr, taps["disp_right_wta"]), describe("disp_right_wta", dr, taps["disp_right_wta"])
+    assert same(a, want), describe("disp_final", a, want)
