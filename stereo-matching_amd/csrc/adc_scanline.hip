@@ -132,14 +132,20 @@ __device__ __forceinline__ float dpp_f(float old, float src) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xf, 0xf, false));
 }
 
-// min over the 64 lanes; every lane returns the result.
+// min over the 64 lanes; every lane returns the result. Six DPP steps with the lane shuffle folded into
+// the v_min itself (a lane without a source keeps its value); written out because the compiler emits a
+// copy, a move-DPP, a canonicalising max and the min per step -- on the serial critical path of every
+// path pixel. A VGPR written by a VALU op needs two wait states before a DPP op reads it.
 __device__ __forceinline__ float wave_min(float v) {
-    v = fminf(v, dpp_f<0x111>(v, v));  // row_shr:1
-    v = fminf(v, dpp_f<0x112>(v, v));  // row_shr:2
-    v = fminf(v, dpp_f<0x114>(v, v));  // row_shr:4
-    v = fminf(v, dpp_f<0x118>(v, v));  // row_shr:8   -> lane 15 of each row holds the row minimum
-    v = fminf(v, dpp_f<0x142>(v, v));  // row_bcast:15 -> rows 1..3 fold in the previous row
-    v = fminf(v, dpp_f<0x143>(v, v));  // row_bcast:31 -> lane 63 holds the wave minimum
+    asm volatile(
+        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"   // lane 15 of each row: row minimum
+        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xf bank_mask:0xf\n\t" // rows 1..3 fold in the previous row
+        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xf bank_mask:0xf\n\t" // lane 63: wave minimum
+        "s_nop 0"
+        : "+v"(v));
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
@@ -165,9 +171,12 @@ __device__ __forceinline__ void store_vec(float *p, const float (&v)[NV]) {
     } else if constexpr (NV == 2) {
         *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[1]);
     } else {
+        typedef float f4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int q = 0; q < NV / 4; q++)
-            reinterpret_cast<float4 *>(p)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        for (int q = 0; q < NV / 4; q++) {
+            f4 t = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+            reinterpret_cast<f4 *>(p)[q] = t;
+        }
     }
 }
 
@@ -212,15 +221,15 @@ template <int NV, bool WTA> struct ScanCfg {
 };
 
 __device__ __forceinline__ int wave_min_i32(int v) {
-    auto d = [](int old, int src, auto ctrl) {
-        return __builtin_amdgcn_update_dpp(old, src, decltype(ctrl)::value, 0xf, 0xf, false);
-    };
-    v = min(v, d(v, v, std::integral_constant<int, 0x111>()));
-    v = min(v, d(v, v, std::integral_constant<int, 0x112>()));
-    v = min(v, d(v, v, std::integral_constant<int, 0x114>()));
-    v = min(v, d(v, v, std::integral_constant<int, 0x118>()));
-    v = min(v, d(v, v, std::integral_constant<int, 0x142>()));
-    v = min(v, d(v, v, std::integral_constant<int, 0x143>()));
+    asm volatile(
+        "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0"
+        : "+v"(v));
     return __builtin_amdgcn_readlane(v, 63);
 }
 
@@ -289,10 +298,13 @@ k_scanline(const float *__restrict__ src, float *__restrict__ dst, const uint32_
     auto read_slot = [&](int s, float (&v)[NV], uint32_t &bits, uint32_t &f1) {
         const uint32_t slot = ring_off + (uint32_t)(s % C::RS) * C::SLOT_B;
         lds_read_vec<NV>(slot + (uint32_t)k0 * 4, v);
+        // raw record words: they are decoded (shift / mask) where they are used, one path pixel later,
+        // so that nothing waits for these reads before the current pixel has been computed
         if constexpr (NV == 16) bits = lds_read<uint16_t>(slot + C::DATA_B + 2 * lane);
-        else bits = (uint32_t)lds_read<uint8_t>(slot + C::DATA_B + ((lane * NV) >> 3)) >> ((lane * NV) & 7);
-        f1 = lds_read<uint32_t>(slot + C::DATA_B + 8 * NV) & 1u;
+        else bits = (uint32_t)lds_read<uint8_t>(slot + C::DATA_B + ((lane * NV) >> 3));
+        f1 = lds_read<uint32_t>(slot + C::DATA_B + 8 * NV);
     };
+    const int bshift = NV == 16 ? 0 : (lane * NV) & 7;
 
     // ---- path head: dst = src, Lp = src
     float Lp[NV];
@@ -345,15 +357,18 @@ k_scanline(const float *__restrict__ src, float *__restrict__ dst, const uint32_
     uint32_t cbits, cf1;
     read_slot(1, cur, cbits, cf1);
 
-    float *outp = dst + (size_t)(pix0 + pstep) * Dp + koff;
+    float *outp = dst + (size_t)(pix0 + pstep) * Dp + koff;   // output of the next pixel to store
     const ptrdiff_t ostep = pstep * (ptrdiff_t)Dp;
-    for (int s = 1; s < LEN; s++, outp += ostep) {
-        // (A) fill of pixel s+RS-1 into the slot pixel s-1 occupied (its reads completed an iteration ago)
+
+    for (int s = 1; s < LEN; s++) {
+        // (A) fill of pixel s+RS-1 into the slot pixel s-1 occupied (its reads completed an iteration ago).
+        //     (Issuing the fills of four consecutive pixels together every fourth step, and likewise the
+        //     stores, was measured: no gain.)
         const int t = s + C::RS - 1;
         if (t < LEN) issue_fill(t);
         // (B) pixel s+1 must have landed. In steady state the operations issued after its fill are
-        //     (RS-2) x (fill + store) groups -- exactly WAITN; near the end of the path that count shrinks,
-        //     so drain instead.
+        //     (RS-2) x (fill + store) groups -- exactly WAITN; near the end of the path that count
+        //     shrinks, so drain instead.
         if (t < LEN && counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::WAITN) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // (C) start reading pixel s+1 while pixel s is computed
@@ -363,8 +378,10 @@ k_scanline(const float *__restrict__ src, float *__restrict__ dst, const uint32_
         for (int j = 0; j < NV; j++) nxt[j] = 0.0f;
         if (s + 1 < LEN) read_slot(s + 1, nxt, nbits, nf1);
         // (D) the recurrence for pixel s
-        const float P1a = cf1 ? sp.P1[1] : sp.P1[0], P1b = cf1 ? sp.P1[2] : sp.P1[1];
-        const float P2a = cf1 ? sp.P2[1] : sp.P2[0], P2b = cf1 ? sp.P2[2] : sp.P2[1];
+        const bool d1hi = cf1 & 1u;
+        const uint32_t kbits = cbits >> bshift;
+        const float P1a = d1hi ? sp.P1[1] : sp.P1[0], P1b = d1hi ? sp.P1[2] : sp.P1[1];
+        const float P2a = d1hi ? sp.P2[1] : sp.P2[0], P2b = d1hi ? sp.P2[2] : sp.P2[1];
         const float up = dpp_f<0x138>(ADC_LARGE_F, Lp[NV - 1]);  // wave_shr:1 -> Lp[k0-1]
         const float dn = dpp_f<0x130>(ADC_LARGE_F, Lp[0]);       // wave_shl:1 -> Lp[k0+NV]
         const float l4a = minLp + P2a, l4b = minLp + P2b;
@@ -372,7 +389,7 @@ k_scanline(const float *__restrict__ src, float *__restrict__ dst, const uint32_
         float lm = ADC_LARGE_F;
 #pragma unroll
         for (int j = 0; j < NV; j++) {
-            const bool hi = (cbits >> j) & 1u;
+            const bool hi = (kbits >> j) & 1u;
             const float P1 = hi ? P1b : P1a;
             const float l1 = Lp[j];
             const float l2 = (j == 0 ? up : Lp[j - 1]) + P1;
@@ -383,11 +400,12 @@ k_scanline(const float *__restrict__ src, float *__restrict__ dst, const uint32_
             nw[j] = (FULL || (active && k0 + j < D)) ? v : ADC_LARGE_F;
             lm = fminf(lm, nw[j]);
         }
-        if (active) {
+        {
             float o[NV];
 #pragma unroll
             for (int j = 0; j < NV; j++) o[j] = (FULL || k0 + j < D) ? nw[j] : 0.0f;
-            store_vec<NV>(outp, o);
+            if (active) store_vec<NV>(outp, o);
+            outp += ostep;
         }
 #pragma unroll
         for (int j = 0; j < NV; j++) Lp[j] = nw[j];
