@@ -54,6 +54,7 @@ struct adc_handle {
     uint8_t *occ = nullptr, *mis = nullptr, *edge = nullptr;
     uint32_t *list_mis = nullptr, *list_occ = nullptr, *counters = nullptr;
     float *newval = nullptr;
+    short *binmap = nullptr;       // histogram bin of every pixel of the current disparity map (voting), -1 = none
     // debug snapshots
     float *snap_wta_l = nullptr, *snap_outlier = nullptr, *snap_voting = nullptr, *snap_interp = nullptr;
     uint8_t *snap_occ = nullptr, *snap_mis = nullptr;
@@ -175,6 +176,7 @@ int do_initialize(adc_handle *h, int32_t W, int32_t H, const adc_option *opt) {
     A(h->occ, npx); A(h->mis, npx); A(h->edge, npx);
     A(h->list_mis, npx); A(h->list_occ, npx); A(h->counters, 4);
     A(h->newval, 2 * npx);
+    A(h->binmap, npx);
     A(h->tap_u64, npx);
 #undef A
     if ((rc = host_alloc(h, &h->h_bgr_l, npx * 3))) return rc;
@@ -312,7 +314,7 @@ int enqueue_match(adc_handle *h, const uint8_t *d_l, const uint8_t *d_r, float *
     mark(ADC_STAGE_REFINE);
     float *cur = h->disp_a, *oth = h->disp_b;
     if (o.do_lr_check) {
-        launch_outlier(cur, h->disp_r, oth, h->occ, h->mis, h->list_mis, h->list_occ, h->counters, g.W, g.H,
+        launch_outlier(cur, h->disp_r, oth, h->occ, h->mis, h->binmap, h->list_mis, h->list_occ, h->counters, g,
                        o.lrcheck_thres, s);
         std::swap(cur, oth);
     } else {
@@ -323,9 +325,9 @@ int enqueue_match(adc_handle *h, const uint8_t *d_l, const uint8_t *d_r, float *
     snap(h->snap_mis, h->mis, npx);
     if (o.do_filling) {  // drives both voting and interpolation (ADC/ADCensusStereo.cu:195-196)
         for (int it = 0; it < 5; it++) {  // IterativeNums (ADC/config.h:46): mismatch pass, then occlusion pass
-            launch_region_voting_pass(cur, h->mis, h->list_mis, h->counters + 0, h->newval, pl.arms, g, o.irv_ts,
+            launch_region_voting_pass(cur, h->binmap, h->mis, h->list_mis, h->counters + 0, h->newval, pl.arms, g, o.irv_ts,
                                       o.irv_th, s);
-            launch_region_voting_pass(cur, h->occ, h->list_occ, h->counters + 1, h->newval, pl.arms, g, o.irv_ts,
+            launch_region_voting_pass(cur, h->binmap, h->occ, h->list_occ, h->counters + 1, h->newval, pl.arms, g, o.irv_ts,
                                       o.irv_th, s);
         }
     }

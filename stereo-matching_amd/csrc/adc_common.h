@@ -76,11 +76,11 @@ struct RefineBufs {
     float *newval;                   // one pending value per list entry (mis list first, then occ)
     const double *ray_dy, *ray_dx;   // [16][maxlen] products m*sin, m*cos
 };
-void launch_outlier(const float *dl, const float *dr, float *out, uint8_t *occ, uint8_t *mis,
+void launch_outlier(const float *dl, const float *dr, float *out, uint8_t *occ, uint8_t *mis, short *binmap,
                     uint32_t *list_mis, uint32_t *list_occ, uint32_t *counters,
-                    int W, int H, float thres, hipStream_t s);
+                    const Geom &g, float thres, hipStream_t s);
 void launch_clear_masks(uint8_t *occ, uint8_t *mis, uint32_t *counters, size_t n, hipStream_t s);
-void launch_region_voting_pass(float *disp, uint8_t *mask, const uint32_t *list, const uint32_t *count,
+void launch_region_voting_pass(float *disp, short *binmap, uint8_t *mask, const uint32_t *list, const uint32_t *count,
                                float *newval, const uint32_t *arms, const Geom &g, int tau_s, float tau_h,
                                hipStream_t s);
 void launch_interpolate(float *disp, const uint8_t *occ, const uint8_t *mis,

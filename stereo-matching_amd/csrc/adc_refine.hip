@@ -15,29 +15,30 @@ namespace adc {
 // lround() of the reference: round half away from zero.
 __device__ __forceinline__ int lround_f(float v) { return (int)roundf(v); }
 
-// Append `value` to a list for every lane with `flag` set: one atomic per wavefront reserves the
-// slots, each flagged lane takes the slot given by its rank among the flagged lanes.
-__device__ __forceinline__ void wave_append(bool flag, uint32_t *__restrict__ list, uint32_t *counter, uint32_t value) {
-    const unsigned long long m = __ballot(flag);
-    if (m == 0) return;
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)m) - 1;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
-    base = __shfl(base, leader, 64);
-    if (flag) list[base + __popcll(m & ((1ull << lane) - 1ull))] = value;
+// Disparity histogram bin of a map entry as the voting step sees it: lround(d) - dmin when the value is
+// valid and inside [0, D), else -1 (RegionVotingCuda's guards, ADC/multistep_refiner.cu:405-409).
+__device__ __forceinline__ short vote_bin(float d, int dmin, int D) {
+    if (d == ADC_INF) return -1;
+    const int b = lround_f(d) - dmin;
+    return (b >= 0 && b < D) ? (short)b : (short)-1;
 }
 
 // ---- outlier detection (OutlierDetectionCuda, ADC/multistep_refiner.cu:70-156) --------------------
-__global__ void __launch_bounds__(256)
+// 64 x 16 pixel tile per 1024-thread workgroup. Flagged pixels are appended to the mismatch / occlusion
+// lists with one atomic per workgroup and list (all appends hit the same two counters, and same-address
+// atomics are served one at a time): wave ballots -> per-wave counts in LDS -> one reservation -> ranks.
+#define OUT_WAVES 16
+__global__ void __launch_bounds__(64 * OUT_WAVES)
 k_outlier(const float *__restrict__ dl, const float *__restrict__ dr, float *__restrict__ out,
-          uint8_t *__restrict__ occ, uint8_t *__restrict__ mis, uint32_t *__restrict__ list_mis,
-          uint32_t *__restrict__ list_occ, uint32_t *__restrict__ counters, int W, int H, float thres) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (y >= H) return;               // wave-uniform
-    const bool in = x < W;
-    const size_t i = (size_t)y * W + (in ? x : 0);
+          uint8_t *__restrict__ occ, uint8_t *__restrict__ mis, short *__restrict__ binmap,
+          uint32_t *__restrict__ list_mis, uint32_t *__restrict__ list_occ, uint32_t *__restrict__ counters,
+          int W, int H, int dmin, int D, float thres) {
+    __shared__ uint32_t s_off[2][OUT_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane;
+    const int y = blockIdx.y * OUT_WAVES + wave;
+    const bool in = x < W && y < H;
+    const size_t i = in ? (size_t)y * W + x : 0;
     const float d = dl[i];
     float o = d;
     bool is_occ = false, is_mis = false;
@@ -68,17 +69,37 @@ k_outlier(const float *__restrict__ dl, const float *__restrict__ dr, float *__r
         out[i] = o;
         occ[i] = is_occ;
         mis[i] = is_mis;
+        binmap[i] = vote_bin(o, dmin, D);
     }
-    wave_append(is_mis, list_mis, &counters[0], (uint32_t)i);
-    wave_append(is_occ, list_occ, &counters[1], (uint32_t)i);
+    const unsigned long long m_mis = __ballot(is_mis), m_occ = __ballot(is_occ);
+    if (lane == 0) {
+        s_off[0][wave] = (uint32_t)__popcll(m_mis);
+        s_off[1][wave] = (uint32_t)__popcll(m_occ);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {            // one thread per list: reserve, then turn the counts into offsets
+        uint32_t tot = 0;
+        for (int w = 0; w < OUT_WAVES; w++) tot += s_off[threadIdx.x][w];
+        uint32_t base = tot ? atomicAdd(&counters[threadIdx.x], tot) : 0u;
+        for (int w = 0; w < OUT_WAVES; w++) {
+            const uint32_t c = s_off[threadIdx.x][w];
+            s_off[threadIdx.x][w] = base;
+            base += c;
+        }
+    }
+    __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (is_mis) list_mis[s_off[0][wave] + (uint32_t)__popcll(m_mis & below)] = (uint32_t)i;
+    if (is_occ) list_occ[s_off[1][wave] + (uint32_t)__popcll(m_occ & below)] = (uint32_t)i;
 }
 
-void launch_outlier(const float *dl, const float *dr, float *out, uint8_t *occ, uint8_t *mis,
+void launch_outlier(const float *dl, const float *dr, float *out, uint8_t *occ, uint8_t *mis, short *binmap,
                     uint32_t *list_mis, uint32_t *list_occ, uint32_t *counters,
-                    int W, int H, float thres, hipStream_t s) {
+                    const Geom &g, float thres, hipStream_t s) {
     hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), s);
-    dim3 grid((W + 63) / 64, (H + 3) / 4);
-    k_outlier<<<grid, dim3(256), 0, s>>>(dl, dr, out, occ, mis, list_mis, list_occ, counters, W, H, thres);
+    dim3 grid((g.W + 63) / 64, (g.H + OUT_WAVES - 1) / OUT_WAVES);
+    k_outlier<<<grid, dim3(64 * OUT_WAVES), 0, s>>>(dl, dr, out, occ, mis, binmap, list_mis, list_occ, counters,
+                                                    g.W, g.H, g.dmin, g.D, thres);
 }
 
 void launch_clear_masks(uint8_t *occ, uint8_t *mis, uint32_t *counters, size_t n, hipStream_t s) {
@@ -94,9 +115,9 @@ void launch_clear_masks(uint8_t *occ, uint8_t *mis, uint32_t *counters, size_t n
 // that their loads are in flight together instead of one dependent round trip per row.
 #define VOTE_ROWS 8
 __global__ void __launch_bounds__(64)
-k_vote(const float *__restrict__ disp, const uint8_t *__restrict__ mask, const uint32_t *__restrict__ list,
-       const uint32_t *__restrict__ count, float *__restrict__ newval, const uint32_t *__restrict__ arms,
-       int W, int dmin, int D, int tau_s, float tau_h) {
+k_vote(const float *__restrict__ disp, const short *__restrict__ binmap, const uint8_t *__restrict__ mask,
+       const uint32_t *__restrict__ list, const uint32_t *__restrict__ count, float *__restrict__ newval,
+       const uint32_t *__restrict__ arms, int W, int dmin, int D, int tau_s, float tau_h) {
     extern __shared__ int hist[];
     const int lane = threadIdx.x;
     const uint32_t n = *count;
@@ -115,38 +136,30 @@ k_vote(const float *__restrict__ disp, const uint8_t *__restrict__ mask, const u
                 uint32_t arow = 0;
                 if (lane < nr) arow = arms[qrow + (size_t)lane * W];
                 for (int t0 = 0; t0 < nr; t0 += VOTE_ROWS) {
-                    float da[VOTE_ROWS], db[VOTE_ROWS];
+                    short ba[VOTE_ROWS], bb[VOTE_ROWS];
                     bool any_b = false;
 #pragma unroll
                     for (int u = 0; u < VOTE_ROWS; u++) {
-                        da[u] = ADC_INF;
-                        db[u] = ADC_INF;
+                        ba[u] = -1;
+                        bb[u] = -1;
                         if (t0 + u < nr) {                                   // uniform
                             const uint32_t a2 = __builtin_amdgcn_readlane(arow, t0 + u);
                             const int l2 = a2 & 0xff, r2 = (a2 >> 8) & 0xff;
-                            const float *row = disp + qrow + (size_t)(t0 + u) * W - l2;
-                            if (lane <= l2 + r2) da[u] = row[lane];
+                            const short *row = binmap + qrow + (size_t)(t0 + u) * W - l2;
+                            if (lane <= l2 + r2) ba[u] = row[lane];
                             if (l2 + r2 >= 64) {                             // uniform, spans longer than a wave
                                 any_b = true;
-                                if (lane + 64 <= l2 + r2) db[u] = row[lane + 64];
+                                if (lane + 64 <= l2 + r2) bb[u] = row[lane + 64];
                             }
                         }
                     }
 #pragma unroll
-                    for (int u = 0; u < VOTE_ROWS; u++) {
-                        if (da[u] != ADC_INF) {
-                            const int bin = lround_f(da[u]) - dmin;
-                            if (bin >= 0 && bin < D) atomicAdd(&hist[bin], 1);
-                        }
-                    }
+                    for (int u = 0; u < VOTE_ROWS; u++)
+                        if (ba[u] >= 0) atomicAdd(&hist[ba[u]], 1);
                     if (any_b) {
 #pragma unroll
-                        for (int u = 0; u < VOTE_ROWS; u++) {
-                            if (db[u] != ADC_INF) {
-                                const int bin = lround_f(db[u]) - dmin;
-                                if (bin >= 0 && bin < D) atomicAdd(&hist[bin], 1);
-                            }
-                        }
+                        for (int u = 0; u < VOTE_ROWS; u++)
+                            if (bb[u] >= 0) atomicAdd(&hist[bb[u]], 1);
                     }
                 }
             }
@@ -175,25 +188,27 @@ k_vote(const float *__restrict__ disp, const uint8_t *__restrict__ mask, const u
 }
 
 __global__ void __launch_bounds__(256)
-k_apply(float *__restrict__ disp, uint8_t *__restrict__ mask, const uint32_t *__restrict__ list,
-        const uint32_t *__restrict__ count, const float *__restrict__ newval) {
+k_apply(float *__restrict__ disp, short *__restrict__ binmap, uint8_t *__restrict__ mask,
+        const uint32_t *__restrict__ list, const uint32_t *__restrict__ count, const float *__restrict__ newval,
+        int dmin, int D) {
     const uint32_t n = *count;
     for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
         const float v = newval[e];
         if (v != ADC_INF) {
             const uint32_t p = list[e];
             disp[p] = v;
+            binmap[p] = vote_bin(v, dmin, D);
             mask[p] = 0;
         }
     }
 }
 
-void launch_region_voting_pass(float *disp, uint8_t *mask, const uint32_t *list, const uint32_t *count,
+void launch_region_voting_pass(float *disp, short *binmap, uint8_t *mask, const uint32_t *list, const uint32_t *count,
                                float *newval, const uint32_t *arms, const Geom &g, int tau_s, float tau_h,
                                hipStream_t s) {
-    k_vote<<<dim3(8192), dim3(64), (size_t)g.D * sizeof(int), s>>>(disp, mask, list, count, newval, arms,
+    k_vote<<<dim3(8192), dim3(64), (size_t)g.D * sizeof(int), s>>>(disp, binmap, mask, list, count, newval, arms,
                                                                   g.W, g.dmin, g.D, tau_s, tau_h);
-    k_apply<<<dim3(512), dim3(256), 0, s>>>(disp, mask, list, count, newval);
+    k_apply<<<dim3(512), dim3(256), 0, s>>>(disp, binmap, mask, list, count, newval, g.dmin, g.D);
 }
 
 // ---- proper interpolation (FillDisp, ADC/multistep_refiner.cu:543-633) ------------------------------
