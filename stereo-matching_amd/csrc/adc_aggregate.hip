@@ -196,6 +196,212 @@ k_agg_ring(const float *__restrict__ src, float *__restrict__ dst, const uint32_
     }
 }
 
+// ---- two adjacent positions per wave ------------------------------------------------------------------
+// The windows of two neighbouring positions of a scanline overlap almost entirely. A wave that owns
+// both reads every ring slot of the overlap once and adds it to both running sums (two independent
+// dependency chains that interleave), then finishes the few terms only one of them has. Each sum
+// still receives exactly its own terms in ascending position order. Per output this halves the LDS
+// reads, the barriers and the per-iteration bookkeeping -- the kernel is bound by instruction issue.
+//
+// sum of n consecutive ring slots starting at slot s (no wrap inside) added to one / two chains
+template <int VEC>
+__device__ __forceinline__ void span1(typename VecT<VEC>::T &acc, const float *rl, int s, int n) {
+    typedef typename VecT<VEC>::T vec_t;
+    constexpr int SLOT = 64 * VEC;
+    const float *q = rl + s * SLOT;
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+        vec_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = ring_read<vec_t>(q + (i + u) * SLOT);
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += v[u];
+    }
+    for (; i < n; i++) acc += ring_read<vec_t>(q + i * SLOT);
+}
+template <int VEC>
+__device__ __forceinline__ void span2(typename VecT<VEC>::T &a0, typename VecT<VEC>::T &a1, const float *rl, int s, int n) {
+    typedef typename VecT<VEC>::T vec_t;
+    constexpr int SLOT = 64 * VEC;
+    const float *q = rl + s * SLOT;
+    int i = 0;
+    for (; i + 16 <= n; i += 16) {
+        vec_t v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) v[u] = ring_read<vec_t>(q + (i + u) * SLOT);
+#pragma unroll
+        for (int u = 0; u < 16; u++) { a0 += v[u]; a1 += v[u]; }
+    }
+    for (; i + 4 <= n; i += 4) {
+        vec_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = ring_read<vec_t>(q + (i + u) * SLOT);
+#pragma unroll
+        for (int u = 0; u < 4; u++) { a0 += v[u]; a1 += v[u]; }
+    }
+    for (; i < n; i++) {
+        const vec_t v = ring_read<vec_t>(q + i * SLOT);
+        a0 += v;
+        a1 += v;
+    }
+}
+// the same over virtual slots vs .. vs+n-1 of an R-slot ring (vs in (-R, 2R)): split at the wrap
+template <int VEC>
+__device__ __forceinline__ void range1(typename VecT<VEC>::T &acc, const float *rl, int vs, int n, int R) {
+    if (n <= 0) return;
+    int s = vs < 0 ? vs + R : (vs >= R ? vs - R : vs);
+    const int n1 = min(n, R - s);
+    span1<VEC>(acc, rl, s, n1);
+    if (n > n1) span1<VEC>(acc, rl, 0, n - n1);
+}
+template <int VEC>
+__device__ __forceinline__ void range2(typename VecT<VEC>::T &a0, typename VecT<VEC>::T &a1, const float *rl, int vs, int n, int R) {
+    if (n <= 0) return;
+    int s = vs < 0 ? vs + R : (vs >= R ? vs - R : vs);
+    const int n1 = min(n, R - s);
+    span2<VEC>(a0, a1, rl, s, n1);
+    if (n > n1) span2<VEC>(a0, a1, rl, 0, n - n1);
+}
+
+// Workgroup iteration i: wave w produces positions o0 + 2w and o0 + 2w + 1 (B = 32 per iteration);
+// the fills of the block iteration i+1 adds to the window are issued first and must have landed by the
+// end of the iteration: they are then older than exactly the two stores that follow them.
+// Ring: R >= 2*cap + 2*B slots (any number; slots are tracked as running counters, not by masking).
+#define PAIR_B (2 * AGG_WAVES)
+template <int VEC, bool DIV>
+__global__ void __launch_bounds__(AGG_WAVES * 64)
+k_agg_pair(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ arms,
+           const uint32_t *__restrict__ cnt, int W, int H, int Dp, int vertical, int seglen, int cap, int R) {
+    typedef typename VecT<VEC>::T vec_t;
+    constexpr int SLOT = 64 * VEC;
+    constexpr int B = PAIR_B;
+    extern __shared__ __align__(16) float ring[];  // R x SLOT
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kc = blockIdx.x * SLOT;
+    const int line = blockIdx.y;
+    const int LEN = vertical ? H : W;
+    const int s0 = blockIdx.z * seglen;
+    if (s0 >= LEN) return;
+    const int s1 = min(LEN, s0 + seglen);
+    const int in_lo = max(0, s0 - cap), in_hi = min(LEN, s1 + cap);
+    const int mstride = vertical ? W * Dp : Dp;
+    const int astride = vertical ? W : 1;
+    const size_t lbase = (vertical ? (size_t)line * Dp : (size_t)line * W * Dp) + (size_t)kc;
+    const size_t abase = vertical ? (size_t)line : (size_t)line * W;
+    const int sh_neg = vertical ? 16 : 0, sh_pos = vertical ? 24 : 8;
+    bool fok[VEC];
+#pragma unroll
+    for (int h = 0; h < VEC; h++) fok[h] = kc + h * 64 + lane < Dp;
+    const float *fsrc = src + lbase + lane;
+    const bool kok = kc + lane * VEC < Dp;
+    const float *rl = ring + lane * VEC;
+
+    // prologue: input position in_lo + j lands in slot j; everything block 0 reads
+    {
+        const int pro_n = min(in_hi, s0 + B + cap) - in_lo;     // <= R - B
+        const float *g = fsrc + (size_t)(in_lo + wave) * mstride;
+        for (int j = wave; j < pro_n; j += AGG_WAVES, g += (ptrdiff_t)AGG_WAVES * mstride) {
+#pragma unroll
+            for (int h = 0; h < VEC; h++)
+                if (fok[h]) ring_fill(g + h * 64, ring + j * SLOT + h * 64);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    int o = s0 + 2 * wave;                        // first of this wave's two positions
+    int qo = s0 - in_lo + 2 * wave;               // its ring slot (< R)
+    int qf = s0 - in_lo + B + cap + 2 * wave;     // ring slot of this wave's first fill of the iteration (< R)
+    const ptrdiff_t blk_m = (ptrdiff_t)B * mstride, blk_a = (ptrdiff_t)B * astride;
+    const float *fill_p = fsrc + (size_t)(s0 + B + cap + 2 * wave) * mstride;
+    float *out_p = dst + lbase + lane * VEC + (size_t)o * mstride;
+    const uint32_t *arm_p = arms + abase + (size_t)o * astride;
+    const uint32_t *cnt_p = DIV ? cnt + abase + (size_t)o * astride : nullptr;
+
+    // arms / support counts are fetched (scalar loads) one iteration ahead of their use
+    uint32_t a_cur[2] = {0u, 0u}, c_cur[2] = {1u, 1u};
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        if (o + j < s1) {
+            a_cur[j] = arm_p[j * astride];
+            if (DIV) c_cur[j] = cnt_p[j * astride];
+        }
+    }
+
+    bool fills_live = true;
+    for (int o0 = s0; o0 < s1; o0 += B) {
+        // (a) fills of the block the next iteration adds to the window
+        const int n0 = o0 + B + cap;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            if (n0 + 2 * wave + j < in_hi) {
+                int q = qf + j;
+                if (q >= R) q -= R;
+#pragma unroll
+                for (int h = 0; h < VEC; h++)
+                    if (fok[h]) ring_fill(fill_p + (ptrdiff_t)j * mstride + h * 64, ring + q * SLOT + h * 64);
+            }
+        }
+        uint32_t a_nxt[2] = {0u, 0u}, c_nxt[2] = {1u, 1u};
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            if (o + B + j < s1) {
+                a_nxt[j] = arm_p[blk_a + j * astride];
+                if (DIV) c_nxt[j] = cnt_p[blk_a + j * astride];
+            }
+        }
+        // (b) this wave's two outputs. Windows in virtual ring slots (slot of position o is qo):
+        //     chain 0 = [qo - neg0, qo + pos0], chain 1 = [qo + 1 - neg1, qo + 1 + pos1]
+        if (o < s1) {
+            const bool two = o + 1 < s1;
+            const int b0 = qo - (int)((a_cur[0] >> sh_neg) & 0xff), e0 = qo + (int)((a_cur[0] >> sh_pos) & 0xff);
+            // a missing second position gets an empty window placed after the first one's
+            const int b1 = two ? qo + 1 - (int)((a_cur[1] >> sh_neg) & 0xff) : e0 + 1;
+            const int e1 = two ? qo + 1 + (int)((a_cur[1] >> sh_pos) & 0xff) : e0;
+            vec_t acc0 = {}, acc1 = {};
+            // head: the terms in front of the other chain's first term
+            if (b0 < b1) range1<VEC>(acc0, rl, b0, min(e0, b1 - 1) - b0 + 1, R);
+            else if (b1 < b0) range1<VEC>(acc1, rl, b1, min(e1, b0 - 1) - b1 + 1, R);
+            // middle: the terms both windows hold
+            const int m0 = max(b0, b1), m1 = min(e0, e1);
+            range2<VEC>(acc0, acc1, rl, m0, m1 - m0 + 1, R);
+            // tail: the terms behind the other chain's last term
+            if (e0 > e1) { const int t = max(b0, e1 + 1); range1<VEC>(acc0, rl, t, e0 - t + 1, R); }
+            else if (e1 > e0) { const int t = max(b1, e0 + 1); range1<VEC>(acc1, rl, t, e1 - t + 1, R); }
+            if (DIV) {
+                acc0 = acc0 / (float)c_cur[0];
+                acc1 = acc1 / (float)c_cur[1];
+            }
+            if (kok) {
+                *reinterpret_cast<vec_t *>(out_p) = acc0;
+                if (two) *reinterpret_cast<vec_t *>(out_p + mstride) = acc1;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) { a_cur[j] = a_nxt[j]; c_cur[j] = c_nxt[j]; }
+        // (c) the next block's fills must have landed before anyone reads them. Once a fill has been
+        //     skipped (end of the line / segment) no further fill follows: drain once, then stop waiting.
+        if (fills_live) {
+            if (n0 + B > in_hi) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                fills_live = false;
+            } else {
+                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        o += B;
+        qo += B; if (qo >= R) qo -= R;
+        qf += B; if (qf >= R) qf -= R;
+        fill_p += blk_m;
+        out_p += blk_m;
+        arm_p += blk_a;
+        if (DIV) cnt_p += blk_a;
+    }
+}
+
 // Fallback without LDS (any arm cap): one wave per (position, 64 disparities), spans re-read through
 // the caches. Same addition order.
 template <bool DIV>
@@ -259,6 +465,35 @@ static void launch_ring(const float *src, float *dst, const uint32_t *arms, cons
         k_agg_ring<VEC, false, DEPTH><<<grid, block, lds, s>>>(src, dst, arms, cnt, g.W, g.H, g.Dp, vertical, seglen, max_arm, R - 1);
 }
 
+template <int VEC>
+static void launch_pair(const float *src, float *dst, const uint32_t *arms, const uint32_t *cnt, const Geom &g,
+                        int vertical, int max_arm, hipStream_t s) {
+    const int SLOT = 64 * VEC;
+    const int chunks = (g.Dp + SLOT - 1) / SLOT;
+    const int lines = vertical ? g.W : g.H;
+    const int LEN = vertical ? g.H : g.W;
+    const int R = 2 * max_arm + 2 * PAIR_B;
+    const size_t lds = (size_t)R * SLOT * sizeof(float);
+    int nseg = 1;
+    const long long wgs = (long long)chunks * lines;
+    if (wgs < 4096) nseg = (int)((4096 + wgs - 1) / wgs);
+    int seglen = (LEN + nseg - 1) / nseg;
+    seglen = ((seglen + PAIR_B - 1) / PAIR_B) * PAIR_B;
+    if (seglen < 128) seglen = 128;
+    nseg = (LEN + seglen - 1) / seglen;
+    dim3 grid(chunks, lines, nseg), block(AGG_WAVES * 64);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_agg_pair<VEC, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_agg_pair<VEC, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr_set = true;
+    }
+    if (cnt)
+        k_agg_pair<VEC, true><<<grid, block, lds, s>>>(src, dst, arms, cnt, g.W, g.H, g.Dp, vertical, seglen, max_arm, R);
+    else
+        k_agg_pair<VEC, false><<<grid, block, lds, s>>>(src, dst, arms, cnt, g.W, g.H, g.Dp, vertical, seglen, max_arm, R);
+}
+
 void launch_aggregate_pass(const float *src, float *dst, const uint32_t *arms, const uint32_t *cnt,
                            const Geom &g, int vertical, int max_arm, int variant, hipStream_t s) {
     // deepest fill look-ahead (6, 4 or 2 iterations) whose ring still fits 64 KB of LDS
@@ -272,7 +507,14 @@ void launch_aggregate_pass(const float *src, float *dst, const uint32_t *arms, c
         while (r < 2 * max_arm + (d + 1) * AGG_WAVES) r <<= 1;
         if ((size_t)r * 64 * vec * 4 <= 64 * 1024) { depth = d; R = r; break; }
     }
-    if (variant == 0 && strides_ok && depth) {
+    // two positions per wave when its ring (2*cap + 64 slots) leaves room for two workgroups per CU
+    static const int pair_env = std::getenv("ADC_AGG_PAIR") ? std::atoi(std::getenv("ADC_AGG_PAIR")) : 1;
+    const bool pair_ok = (long long)g.W * g.Dp * (PAIR_B + 2) < (1ll << 31) &&
+                         (size_t)(2 * max_arm + 2 * PAIR_B) * 64 * vec * 4 <= 80 * 1024;
+    if (variant == 0 && pair_env && pair_ok) {
+        if (vec == 2) launch_pair<2>(src, dst, arms, cnt, g, vertical, max_arm, s);
+        else launch_pair<1>(src, dst, arms, cnt, g, vertical, max_arm, s);
+    } else if (variant == 0 && strides_ok && depth) {
 #define ADC_RING(V, D) launch_ring<V, D>(src, dst, arms, cnt, g, vertical, max_arm, R, s)
         if (vec == 2) { if (depth == 6) ADC_RING(2, 6); else if (depth == 4) ADC_RING(2, 4); else ADC_RING(2, 2); }
         else { if (depth == 6) ADC_RING(1, 6); else if (depth == 4) ADC_RING(1, 4); else ADC_RING(1, 2); }
