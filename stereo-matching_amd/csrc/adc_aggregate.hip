@@ -204,46 +204,39 @@ k_agg_ring(const float *__restrict__ src, float *__restrict__ dst, const uint32_
 // reads, the barriers and the per-iteration bookkeeping -- the kernel is bound by instruction issue.
 //
 // sum of n consecutive ring slots starting at slot s (no wrap inside) added to one / two chains
-template <int VEC>
-__device__ __forceinline__ void span1(typename VecT<VEC>::T &acc, const float *rl, int s, int n) {
+// G consecutive slots from q added to one chain (CH == 1) or to both (CH == 2): all reads, then the adds
+template <int VEC, int CH, int G>
+__device__ __forceinline__ void group_add(typename VecT<VEC>::T &a0, typename VecT<VEC>::T &a1, const float *q) {
     typedef typename VecT<VEC>::T vec_t;
     constexpr int SLOT = 64 * VEC;
-    const float *q = rl + s * SLOT;
-    int i = 0;
-    for (; i + 8 <= n; i += 8) {
-        vec_t v[8];
+    vec_t v[G];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = ring_read<vec_t>(q + (i + u) * SLOT);
+    for (int u = 0; u < G; u++) v[u] = ring_read<vec_t>(q + u * SLOT);
 #pragma unroll
-        for (int u = 0; u < 8; u++) acc += v[u];
+    for (int u = 0; u < G; u++) {
+        a0 += v[u];
+        if (CH == 2) a1 += v[u];
     }
-    for (; i < n; i++) acc += ring_read<vec_t>(q + i * SLOT);
+}
+// n consecutive ring slots starting at slot s (no wrap inside): batches of 16, then the remainder as
+// one group each of 8, 4, 2, 1 terms as the bits of n say (four tests instead of a counted loop)
+template <int VEC, int CH>
+__device__ __forceinline__ void span(typename VecT<VEC>::T &a0, typename VecT<VEC>::T &a1, const float *rl, int s, int n) {
+    constexpr int SLOT = 64 * VEC;
+    const float *q = rl + s * SLOT;
+    for (int i = 16; i <= n; i += 16, q += 16 * SLOT) group_add<VEC, CH, 16>(a0, a1, q);
+    if (n & 8) { group_add<VEC, CH, 8>(a0, a1, q); q += 8 * SLOT; }
+    if (n & 4) { group_add<VEC, CH, 4>(a0, a1, q); q += 4 * SLOT; }
+    if (n & 2) { group_add<VEC, CH, 2>(a0, a1, q); q += 2 * SLOT; }
+    if (n & 1) group_add<VEC, CH, 1>(a0, a1, q);
+}
+template <int VEC>
+__device__ __forceinline__ void span1(typename VecT<VEC>::T &acc, const float *rl, int s, int n) {
+    span<VEC, 1>(acc, acc, rl, s, n);
 }
 template <int VEC>
 __device__ __forceinline__ void span2(typename VecT<VEC>::T &a0, typename VecT<VEC>::T &a1, const float *rl, int s, int n) {
-    typedef typename VecT<VEC>::T vec_t;
-    constexpr int SLOT = 64 * VEC;
-    const float *q = rl + s * SLOT;
-    int i = 0;
-    for (; i + 16 <= n; i += 16) {
-        vec_t v[16];
-#pragma unroll
-        for (int u = 0; u < 16; u++) v[u] = ring_read<vec_t>(q + (i + u) * SLOT);
-#pragma unroll
-        for (int u = 0; u < 16; u++) { a0 += v[u]; a1 += v[u]; }
-    }
-    for (; i + 4 <= n; i += 4) {
-        vec_t v[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = ring_read<vec_t>(q + (i + u) * SLOT);
-#pragma unroll
-        for (int u = 0; u < 4; u++) { a0 += v[u]; a1 += v[u]; }
-    }
-    for (; i < n; i++) {
-        const vec_t v = ring_read<vec_t>(q + i * SLOT);
-        a0 += v;
-        a1 += v;
-    }
+    span<VEC, 2>(a0, a1, rl, s, n);
 }
 // the same over virtual slots vs .. vs+n-1 of an R-slot ring (vs in (-R, 2R)): split at the wrap
 template <int VEC>
