@@ -53,6 +53,7 @@ struct adc_handle {
     float *cur_disp = nullptr;        // which of disp_a/disp_b holds the map after edge adjustment
     uint8_t *occ = nullptr, *mis = nullptr, *edge = nullptr;
     uint32_t *list_mis = nullptr, *list_occ = nullptr, *counters = nullptr;
+    uint32_t *list2_mis = nullptr, *list2_occ = nullptr;   // the entries still unfilled after voting
     float *newval = nullptr;
     short *binmap = nullptr;       // histogram bin of every pixel of the current disparity map (voting), -1 = none
     // debug snapshots
@@ -175,6 +176,7 @@ int do_initialize(adc_handle *h, int32_t W, int32_t H, const adc_option *opt) {
     A(h->disp_a, npx); A(h->disp_b, npx); A(h->disp_r, npx); A(h->disp_final, npx);
     A(h->occ, npx); A(h->mis, npx); A(h->edge, npx);
     A(h->list_mis, npx); A(h->list_occ, npx); A(h->counters, 4);
+    A(h->list2_mis, npx); A(h->list2_occ, npx);
     A(h->newval, 2 * npx);
     A(h->binmap, npx);
     A(h->tap_u64, npx);
@@ -333,7 +335,7 @@ int enqueue_match(adc_handle *h, const uint8_t *d_l, const uint8_t *d_r, float *
     }
     snap(h->snap_voting, cur, npx * sizeof(float));
     if (o.do_filling) {
-        launch_interpolate(cur, h->occ, h->mis, h->list_mis, h->list_occ, h->counters, h->newval, pl.pix_l,
+        launch_interpolate(cur, h->occ, h->mis, h->list_mis, h->list_occ, h->list2_mis, h->list2_occ, h->counters, h->newval, pl.pix_l,
                            h->ray_dy, h->ray_dx, h->ray_off, g, h->ray_len, s);
     }
     snap(h->snap_interp, cur, npx * sizeof(float));

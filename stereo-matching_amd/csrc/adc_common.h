@@ -84,9 +84,10 @@ void launch_region_voting_pass(float *disp, short *binmap, uint8_t *mask, const 
                                float *newval, const uint32_t *arms, const Geom &g, int tau_s, float tau_h,
                                hipStream_t s);
 void launch_interpolate(float *disp, const uint8_t *occ, const uint8_t *mis,
-                        const uint32_t *list_mis, const uint32_t *list_occ, const uint32_t *counters,
-                        float *newval, const uint32_t *pix_l, const double *ray_dy, const double *ray_dx,
-                        const uint32_t *ray_off /* may be null */, const Geom &g, int maxlen, hipStream_t s);
+                        const uint32_t *list_mis, const uint32_t *list_occ, uint32_t *list2_mis, uint32_t *list2_occ,
+                        uint32_t *counters, float *newval, const uint32_t *pix_l, const double *ray_dy,
+                        const double *ray_dx, const uint32_t *ray_off /* may be null */, const Geom &g, int maxlen,
+                        hipStream_t s);
 void launch_edge_detect(const float *disp, uint8_t *edge, int W, int H, float thres, hipStream_t s);
 void launch_edge_adjust(const float *disp_in, float *disp_out, const float *cost, const uint8_t *edge,
                         const Geom &g, hipStream_t s);

@@ -211,6 +211,44 @@ void launch_region_voting_pass(float *disp, short *binmap, uint8_t *mask, const 
     k_apply<<<dim3(512), dim3(256), 0, s>>>(disp, binmap, mask, list, count, newval, g.dmin, g.D);
 }
 
+// ---- list compaction ---------------------------------------------------------------------------------
+// After the voting passes most listed pixels are filled. The interpolation walks long rays for the
+// ones that are not, 4 pixels per wavefront, so it runs on lists holding only those.
+// counters: [0] mismatch, [1] occlusion entries in; [2], [3] entries out.
+__global__ void __launch_bounds__(1024)
+k_compact(const uint32_t *__restrict__ list_mis, const uint32_t *__restrict__ list_occ,
+          const uint8_t *__restrict__ mis, const uint8_t *__restrict__ occ, uint32_t *__restrict__ out_mis,
+          uint32_t *__restrict__ out_occ, uint32_t *__restrict__ counters) {
+    __shared__ uint32_t s_off[16];
+    const uint32_t n_mis = counters[0], n_occ = counters[1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t e0 = blockIdx.x * 1024u; e0 < ((n_mis + 1023u) & ~1023u) + n_occ; e0 += gridDim.x * 1024u) {
+        // a block handles entries of one list only: the occlusion entries start at the next multiple of 1024
+        const uint32_t e = e0 + threadIdx.x;
+        const uint32_t mis_end = (n_mis + 1023u) & ~1023u;
+        bool keep = false, from_mis = e0 < mis_end;
+        uint32_t p = 0;
+        if (from_mis) {
+            if (e < n_mis) { p = list_mis[e]; keep = mis[p] != 0; }
+        } else if (e - mis_end < n_occ) {
+            p = list_occ[e - mis_end];
+            keep = occ[p] != 0;
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) s_off[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tot = 0;
+            for (int w = 0; w < 16; w++) tot += s_off[w];
+            uint32_t base = tot ? atomicAdd(&counters[from_mis ? 2 : 3], tot) : 0u;
+            for (int w = 0; w < 16; w++) { const uint32_t c = s_off[w]; s_off[w] = base; base += c; }
+        }
+        __syncthreads();
+        if (keep) (from_mis ? out_mis : out_occ)[s_off[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = p;
+        __syncthreads();
+    }
+}
+
 // ---- proper interpolation (FillDisp, ADC/multistep_refiner.cu:543-633) ------------------------------
 // ray_dy / ray_dx hold the host-computed products m*sin(ang_s), m*cos(ang_s) (double) for the 16
 // directions, so the device only adds and rounds. 16 lanes share one listed pixel, one ray each, and
@@ -255,51 +293,37 @@ k_interp(const float *__restrict__ disp, const uint8_t *__restrict__ occ, const 
         const int y = (int)(p / (uint32_t)W), x = (int)(p - (uint32_t)y * W);
         bool found = false;
         float fd = 0.0f;
-        size_t fq = 0;
+        uint32_t fq = 0;
         bool walking = live && (m || o);
+        // Branch-free body: every lane loads INTERP_STEPS samples (from its own pixel when the sample is
+        // outside the image or the lane has finished), then the flags advance by selects.
         for (int mm = 1; mm < maxlen && __any(walking); mm += INTERP_STEPS) {
             float d[INTERP_STEPS];
-            size_t q[INTERP_STEPS];
+            uint32_t q[INTERP_STEPS];
             bool in[INTERP_STEPS];
-            bool ok = walking;
 #pragma unroll
             for (int u = 0; u < INTERP_STEPS; u++) {
-                d[u] = ADC_INF;
-                q[u] = 0;
-                in[u] = false;
-                if (ok && mm + u < maxlen) {
-                    int yy, xx;
-                    if (INT_TAB) {
-                        const uint32_t o2 = off[mm + u];
-                        yy = y + ((int)o2 >> 16);
-                        xx = x + (int)(short)(o2 & 0xffffu);
-                    } else {
-                        yy = (int)round((double)y + dy[mm + u]);
-                        xx = (int)round((double)x + dx[mm + u]);
-                    }
-                    if (yy < 0 || yy >= H || xx < 0 || xx >= W) {
-                        ok = false;                  // the ray leaves the image: nothing beyond counts
-                    } else {
-                        in[u] = true;
-                        q[u] = (size_t)yy * W + xx;
-                        d[u] = disp[q[u]];
-                    }
+                const int mi = min(mm + u, maxlen - 1);
+                int yy, xx;
+                if (INT_TAB) {
+                    const uint32_t o2 = off[mi];
+                    yy = y + ((int)o2 >> 16);
+                    xx = x + (int)(short)(o2 & 0xffffu);
                 } else {
-                    ok = false;
+                    yy = (int)round((double)y + dy[mi]);
+                    xx = (int)round((double)x + dx[mi]);
                 }
+                in[u] = (mm + u < maxlen) & ((unsigned)yy < (unsigned)H) & ((unsigned)xx < (unsigned)W);
+                q[u] = in[u] ? (uint32_t)yy * (uint32_t)W + (uint32_t)xx : p;
+                d[u] = disp[q[u]];
             }
 #pragma unroll
             for (int u = 0; u < INTERP_STEPS; u++) {
-                if (walking) {
-                    if (!in[u]) {
-                        walking = false;             // left the image or ran out of samples
-                    } else if (d[u] != ADC_INF) {
-                        found = true;
-                        fd = d[u];
-                        fq = q[u];
-                        walking = false;
-                    }
-                }
+                const bool hit = walking & in[u] & (d[u] != ADC_INF);   // first valid sample of the ray
+                found |= hit;
+                fd = hit ? d[u] : fd;
+                fq = hit ? q[u] : fq;
+                walking = walking & in[u] & !hit;                       // the ray ends at the image border too
             }
         }
         // combine the 16 directions of a pixel
@@ -340,18 +364,20 @@ k_apply_interp(float *__restrict__ disp, const uint32_t *__restrict__ list_mis, 
 }
 
 void launch_interpolate(float *disp, const uint8_t *occ, const uint8_t *mis,
-                        const uint32_t *list_mis, const uint32_t *list_occ, const uint32_t *counters,
-                        float *newval, const uint32_t *pix_l, const double *ray_dy, const double *ray_dx,
-                        const uint32_t *ray_off, const Geom &g, int maxlen, hipStream_t s) {
+                        const uint32_t *list_mis, const uint32_t *list_occ, uint32_t *list2_mis, uint32_t *list2_occ,
+                        uint32_t *counters, float *newval, const uint32_t *pix_l, const double *ray_dy,
+                        const double *ray_dx, const uint32_t *ray_off, const Geom &g, int maxlen, hipStream_t s) {
     const size_t npx = (size_t)g.W * g.H;
+    hipMemsetAsync(counters + 2, 0, 2 * sizeof(uint32_t), s);
+    k_compact<<<dim3(1024), dim3(1024), 0, s>>>(list_mis, list_occ, mis, occ, list2_mis, list2_occ, counters);
     const size_t tab = (size_t)16 * maxlen * sizeof(uint32_t);
 #define ADC_INTERP(I, L, LDS) k_interp<I, L><<<dim3(8192), dim3(256), LDS, s>>>( \
-        disp, occ, mis, list_mis, list_occ, counters, newval, pix_l, ray_dy, ray_dx, ray_off, g.W, g.H, maxlen, npx)
+        disp, occ, mis, list2_mis, list2_occ, counters + 2, newval, pix_l, ray_dy, ray_dx, ray_off, g.W, g.H, maxlen, npx)
     if (!ray_off) ADC_INTERP(false, false, 0);
     else if (tab <= 48 * 1024) ADC_INTERP(true, true, tab);
     else ADC_INTERP(true, false, 0);
 #undef ADC_INTERP
-    k_apply_interp<<<dim3(512), dim3(256), 0, s>>>(disp, list_mis, list_occ, counters, newval, npx);
+    k_apply_interp<<<dim3(512), dim3(256), 0, s>>>(disp, list2_mis, list2_occ, counters + 2, newval, npx);
 }
 
 // ---- sobel edges (EdgeDetectCuda, ADC/multistep_refiner.cu:161-180) ---------------------------------
