@@ -80,6 +80,8 @@ EXPORTS = [
     "adc_match_device", "adc_synchronize", "adc_set_debug_taps", "adc_set_profiling", "adc_stage_times",
     "adc_aggr_kernel_stats", "adc_buffer_bytes", "adc_get_buffer", "adc_match_batch", "adc_last_error",
 ]
+# ... and include/adcensus_harness.h
+HARNESS_EXPORTS = ["adc_png_read", "adc_image_free", "adc_png_write_gray", "adc_disparity_to_u8", "adc_eval_0103"]
 
 _lib = None
 
@@ -113,6 +115,13 @@ def lib():
         L.adc_match_batch.argtypes = [C.c_void_p]
         L.adc_last_error.restype = C.c_char_p
         L.adc_last_error.argtypes = [C.c_void_p]
+        L.adc_png_read.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.adc_image_free.restype = None
+        L.adc_image_free.argtypes = [C.c_void_p]
+        L.adc_png_write_gray.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
+        L.adc_disparity_to_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.adc_eval_0103.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_double,
+                                    C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
         _lib = L
     return _lib
 
@@ -240,3 +249,44 @@ def match_batch(lefts, rights, option, devices):
     if rc != ADC_OK:
         raise RuntimeError("adc_match_batch failed (%d): %s" % (rc, lib().adc_last_error(None).decode()))
     return disps
+
+
+# -- harness (include/adcensus_harness.h): what the reference's caller does around Match() --------------
+def png_read(path, channels=3):
+    """8-bit PNG -> BGR u8[H][W][3] (channels=3, what cv::imread hands the reference) or gray u8[H][W]."""
+    p, w, h = C.c_void_p(), C.c_int(), C.c_int()
+    rc = lib().adc_png_read(os.fsencode(path), channels, C.byref(p), C.byref(w), C.byref(h))
+    if rc != 0:
+        raise IOError("adc_png_read(%s) failed (%d)" % (path, rc))
+    n = w.value * h.value * channels
+    a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n,)).copy()
+    lib().adc_image_free(p)
+    return a.reshape((h.value, w.value, 3) if channels == 3 else (h.value, w.value))
+
+
+def png_write_gray(path, gray):
+    g = np.ascontiguousarray(gray, np.uint8)
+    rc = lib().adc_png_write_gray(os.fsencode(path), g.ctypes.data, g.shape[1], g.shape[0])
+    if rc != 0:
+        raise IOError("adc_png_write_gray(%s) failed (%d)" % (path, rc))
+
+
+def disparity_to_u8(disp):
+    """The reference's SaveDisparityMap normalisation (main.cpp:443-468)."""
+    d = np.ascontiguousarray(disp, np.float32)
+    out = np.empty(d.shape, np.uint8)
+    rc = lib().adc_disparity_to_u8(d.ctypes.data, d.shape[1], d.shape[0], out.ctypes.data)
+    assert rc == 0
+    return out
+
+
+def eval_0103(disp, gt_u8, gt_div=4.0, delta=2.0, seconds=1.0):
+    """The reference's PerformanceEval0103 (performance_eval.cpp:218-253): (RMS, PEP, Mde)."""
+    d = np.ascontiguousarray(disp, np.float32)
+    g = np.ascontiguousarray(gt_u8, np.uint8)
+    assert d.shape == g.shape
+    rms, pep, mde = C.c_float(), C.c_float(), C.c_float()
+    rc = lib().adc_eval_0103(d.ctypes.data, g.ctypes.data, d.shape[1], d.shape[0], gt_div, delta, seconds,
+                             C.byref(rms), C.byref(pep), C.byref(mde))
+    assert rc == 0
+    return rms.value, pep.value, mde.value

@@ -10,8 +10,8 @@ import numpy as np
 from conftest import ROOT
 
 
-def header_functions():
-    txt = open(os.path.join(ROOT, "include", "adcensus.h")).read()
+def header_functions(name="adcensus.h"):
+    txt = open(os.path.join(ROOT, "include", name)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(adc_[a-z0-9_]+)\s*\(", txt)))
 
@@ -21,6 +21,10 @@ def test_exports_match_header(pkg):
     names = header_functions()
     assert names == sorted(pkg.EXPORTS)
     for n in names:
+        assert hasattr(L, n), n
+    harness = header_functions("adcensus_harness.h")
+    assert harness == sorted(pkg.HARNESS_EXPORTS)
+    for n in harness:
         assert hasattr(L, n), n
 
 

@@ -9,8 +9,8 @@ mkdir -p build/variants lib/variants
 base=$(basename "$file" .hip)
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC "$@" -c "csrc/$base.hip" -o "build/variants/${base}_$name.o"
 objs=""
-for o in build/adc_pre.o build/adc_aggregate.o build/adc_scanline.o build/adc_wta.o build/adc_refine.o build/adc_api.o; do
+for o in build/adc_pre.o build/adc_aggregate.o build/adc_scanline.o build/adc_wta.o build/adc_refine.o build/adc_api.o build/adc_harness.o; do
   if [ "$(basename $o .o)" = "$base" ]; then objs="$objs build/variants/${base}_$name.o"; else objs="$objs $o"; fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "lib/variants/libadc_$name.so" $objs
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "lib/variants/libadc_$name.so" $objs -lz
 echo "built lib/variants/libadc_$name.so"
