@@ -20,6 +20,7 @@
 // by LDS-DMA into a per-wave ring RS pixels ahead of their use, with counted vmcnt waits.
 #include "adc_common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace adc {
@@ -419,6 +420,183 @@ k_scanline(const float *__restrict__ src, float *__restrict__ dst, const uint32_
     }
 }
 
+// ---- two wavefronts per scanline ------------------------------------------------------------------------
+// A pass is a serial chain per scanline, and a horizontal pass over 1080 rows has barely one wavefront
+// per SIMD to run it: every dependent instruction then waits out its full latency. Here a scanline is
+// shared by the two waves of a 128-thread workgroup, each holding half of the disparities (NVW per
+// lane). Per path pixel they exchange, through LDS and one barrier, what crosses the middle: their
+// partial minimum of Lr(p-r, .) and the one cost next to the other half (Lr(p-r, D/2-1) / Lr(p-r, D/2)).
+// min() is exact and commutative, so the results are the same bits as the one-wave kernel's.
+// Only for Dp == D == 128*NVW, passes without the fused WTA.
+template <int NVW> struct ScanCfgSplit {
+    static constexpr int NVF = 2 * NVW;                               // disparities per lane pair = the record's NV
+    static constexpr int DATA_B = 256 * NVW;                          // this wave's half of a pixel's cost vector
+    static constexpr int FLAG_B = ((8 * NVF + 4 + 15) / 16) * 16;     // the pixel's colour-step record (both halves)
+    static constexpr int SLOT_B = DATA_B + FLAG_B;
+    static constexpr int NDMA = NVW >= 4 ? NVW / 4 : NVW;
+    static constexpr int NST = NVW >= 4 ? NVW / 4 : 1;
+    static constexpr int OPS = NDMA + 1 + NST;
+    static constexpr int RS_MEM = NVW <= 4 ? 16 : 8;
+    static constexpr int RS_CNT = 63 / OPS + 2;
+    static constexpr int RS = RS_MEM < RS_CNT ? RS_MEM : RS_CNT;
+    static constexpr int WAITN = (RS - 2) * OPS;
+    static_assert(WAITN <= 63 && RS >= 3, "vmcnt is a 6-bit counter");
+};
+
+template <int NVW, int VERT>
+__global__ void __launch_bounds__(128)
+k_scanline_split(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ rec,
+                 int W, int H, int Dp, int forward, ScanParams sp) {
+    typedef ScanCfgSplit<NVW> C;
+    constexpr int NV = NVW;
+    extern __shared__ __align__(16) uint8_t lds_raw[];
+    const int lane = threadIdx.x & 63;
+    const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0: low disparities, 1: high
+    const int line = blockIdx.x;
+    uint8_t *ring = lds_raw + (size_t)half * C::RS * C::SLOT_B;
+    const uint32_t xch_off = (uint32_t)(uintptr_t)(lds_raw + (size_t)2 * C::RS * C::SLOT_B);   // [parity][half] x {min, edge}
+    const int LEN = VERT ? H : W;
+    const int dir = forward ? 1 : -1;
+    const int kbase = half * 64 * NV;             // first disparity of this wave
+    const int k0 = kbase + lane * NV;
+    const int recw = 2 * C::NVF + 1;
+    const int x0 = VERT ? line : (forward ? 0 : W - 1);
+    const int y0 = VERT ? (forward ? 0 : H - 1) : line;
+    const ptrdiff_t pstep = VERT ? (ptrdiff_t)dir * W : (ptrdiff_t)dir;
+    const ptrdiff_t pix0 = (ptrdiff_t)y0 * W + x0;
+    const ptrdiff_t rshift = (VERT && !forward) ? (ptrdiff_t)W : 0;
+
+    const float *gfill = src + kbase + (NV >= 4 ? 4 * lane : lane);
+    const uint32_t *gflag = rec + lane;
+    const bool flag_lane = lane < recw;
+    auto issue_fill = [&](int s) {
+        const ptrdiff_t p = pix0 + (ptrdiff_t)s * pstep;
+        uint8_t *slot = ring + (s % C::RS) * C::SLOT_B;
+        const float *g = gfill + (size_t)p * Dp;
+#pragma unroll
+        for (int q = 0; q < C::NDMA; q++) {
+            if constexpr (NV >= 4)
+                __builtin_amdgcn_global_load_lds(g + q * 256, (lds_void *)(slot + q * 1024), 16, 0, 0);
+            else
+                __builtin_amdgcn_global_load_lds(g + q * 64, (lds_void *)(slot + q * 256), 4, 0, 0);
+        }
+        if (flag_lane)
+            __builtin_amdgcn_global_load_lds(gflag + (size_t)(p + rshift) * recw, (lds_void *)(slot + C::DATA_B), 4, 0, 0);
+    };
+    const uint32_t ring_off = (uint32_t)(uintptr_t)ring;
+    auto read_slot = [&](int s, float (&v)[NV], uint32_t &bits, uint32_t &f1) {
+        const uint32_t slot = ring_off + (uint32_t)(s % C::RS) * C::SLOT_B;
+        lds_read_vec<NV>(slot + (uint32_t)(lane * NV) * 4, v);
+        if constexpr (NV == 16) bits = lds_read<uint16_t>(slot + C::DATA_B + (k0 >> 3));
+        else bits = (uint32_t)lds_read<uint8_t>(slot + C::DATA_B + (k0 >> 3));
+        f1 = lds_read<uint32_t>(slot + C::DATA_B + 8 * C::NVF);
+    };
+    const int bshift = NV == 16 ? 0 : k0 & 7;
+    // hand {own minimum, own cost next to the other half} over, get the other wave's pair
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const int edge_lane = half ? 0 : 63;
+    auto exchange = [&](int par, float own_min, float edge, float &omin, float &oedge) {
+        if (lane == edge_lane) {
+            typedef volatile f2 __attribute__((address_space(3))) *xp;
+            f2 v = {own_min, edge};
+            *(xp)(uintptr_t)(xch_off + (uint32_t)(par * 2 + half) * 8) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const f2 o = lds_read<f2>(xch_off + (uint32_t)(par * 2 + (1 - half)) * 8);
+        omin = o.x;
+        oedge = o.y;
+    };
+
+    // ---- path head: dst = src, Lp = src
+    float Lp[NV];
+    load_vec<NV>(src + (size_t)pix0 * Dp + k0, Lp);
+    store_vec<NV>(dst + (size_t)pix0 * Dp + k0, Lp);
+    float lmin = Lp[0];
+#pragma unroll
+    for (int j = 1; j < NV; j++) lmin = fminf(lmin, Lp[j]);
+    float minLp, oedge;
+    {
+        const float own = wave_min(lmin);
+        float omin;
+        exchange(0, own, half ? Lp[0] : Lp[NV - 1], omin, oedge);
+        minLp = fminf(own, omin);
+    }
+    if (LEN < 2) return;
+
+    for (int t = 1; t < C::RS && t < LEN; t++) issue_fill(t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float cur[NV];
+    uint32_t cbits, cf1;
+    read_slot(1, cur, cbits, cf1);
+
+    float *outp = dst + (size_t)(pix0 + pstep) * Dp + k0;
+    const ptrdiff_t ostep = pstep * (ptrdiff_t)Dp;
+    for (int s = 1; s < LEN; s++) {
+        const int t = s + C::RS - 1;
+        if (t < LEN) issue_fill(t);
+        if (t < LEN) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::WAITN) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float nxt[NV];
+        uint32_t nbits = 0, nf1 = 0;
+#pragma unroll
+        for (int j = 0; j < NV; j++) nxt[j] = 0.0f;
+        if (s + 1 < LEN) read_slot(s + 1, nxt, nbits, nf1);
+        const bool d1hi = cf1 & 1u;
+        const uint32_t kbits = cbits >> bshift;
+        const float P1a = d1hi ? sp.P1[1] : sp.P1[0], P1b = d1hi ? sp.P1[2] : sp.P1[1];
+        const float P2a = d1hi ? sp.P2[1] : sp.P2[0], P2b = d1hi ? sp.P2[2] : sp.P2[1];
+        // neighbours across lanes; at the seam between the two waves the value the other wave handed over,
+        // at the ends of the disparity range the reference's Large_Float sentinels
+        float up = dpp_f<0x138>(ADC_LARGE_F, Lp[NV - 1]);   // wave_shr:1 -> Lp[k0-1]
+        float dn = dpp_f<0x130>(ADC_LARGE_F, Lp[0]);        // wave_shl:1 -> Lp[k0+NV]
+        if (half) up = lane == 0 ? oedge : up;
+        else dn = lane == 63 ? oedge : dn;
+        const float l4a = minLp + P2a, l4b = minLp + P2b;
+        float nw[NV];
+        float lm = ADC_LARGE_F;
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            const bool hi = (kbits >> j) & 1u;
+            const float P1 = hi ? P1b : P1a;
+            const float l1 = Lp[j];
+            const float l2 = (j == 0 ? up : Lp[j - 1]) + P1;
+            const float l3 = (j == NV - 1 ? dn : Lp[j + 1]) + P1;
+            const float l4 = hi ? l4b : l4a;
+            const float m = fminf(fminf(l1, l2), fminf(l3, l4));
+            nw[j] = (cur[j] + m) / 2.0f;
+            lm = fminf(lm, nw[j]);
+        }
+        store_vec<NV>(outp, nw);
+        outp += ostep;
+#pragma unroll
+        for (int j = 0; j < NV; j++) Lp[j] = nw[j];
+        {
+            const float own = wave_min(lm);
+            float omin;
+            exchange(s & 1, own, half ? Lp[0] : Lp[NV - 1], omin, oedge);
+            minLp = fminf(own, omin);
+        }
+#pragma unroll
+        for (int j = 0; j < NV; j++) cur[j] = nxt[j];
+        cbits = nbits;
+        cf1 = nf1;
+    }
+}
+
+template <int NVW>
+static void launch_split(const float *src, float *dst, const Planes &p, const Geom &g, const ScanParams &sp,
+                         int vertical, int forward, hipStream_t s) {
+    typedef ScanCfgSplit<NVW> C;
+    const int nlines = vertical ? g.W : g.H;
+    const size_t lds = (size_t)2 * C::RS * C::SLOT_B + 64;
+    const uint32_t *rec = vertical ? p.rec_v : (forward ? p.rec_hf : p.rec_hb);
+    if (vertical)
+        k_scanline_split<NVW, 1><<<dim3(nlines), dim3(128), lds, s>>>(src, dst, rec, g.W, g.H, g.Dp, forward, sp);
+    else
+        k_scanline_split<NVW, 0><<<dim3(nlines), dim3(128), lds, s>>>(src, dst, rec, g.W, g.H, g.Dp, forward, sp);
+}
+
 template <int NV, bool WTA>
 static void launch_nv(const float *src, float *dst, float *disp, const Planes &p, const Geom &g, const ScanParams &sp,
                       int vertical, int forward, hipStream_t s) {
@@ -445,6 +623,15 @@ static void launch_nv(const float *src, float *dst, float *disp, const Planes &p
 
 void launch_scanline_pass(const float *src, float *dst, const Planes &p, const Geom &g,
                           const ScanParams &sp, int vertical, int forward, float *disp_wta, hipStream_t s) {
+    // two waves per scanline where a pass has too few scanlines to fill the SIMDs: horizontal passes
+    // (ADC_SCAN_SPLIT: 0 never, 1 horizontal passes, 2 every pass without the fused WTA)
+    static const int split_env = std::getenv("ADC_SCAN_SPLIT") ? std::atoi(std::getenv("ADC_SCAN_SPLIT")) : 1;
+    const bool split_ok = !disp_wta && g.Dp == g.D && (g.NV == 4 || g.NV == 8) && g.D == 64 * g.NV;
+    if (split_ok && (split_env >= 2 || (split_env == 1 && !vertical))) {
+        if (g.NV == 4) launch_split<2>(src, dst, p, g, sp, vertical, forward, s);
+        else launch_split<4>(src, dst, p, g, sp, vertical, forward, s);
+        return;
+    }
 #define ADC_NV(N)                                                                    \
     if (disp_wta) launch_nv<N, true>(src, dst, disp_wta, p, g, sp, vertical, forward, s); \
     else launch_nv<N, false>(src, dst, nullptr, p, g, sp, vertical, forward, s)
