@@ -135,8 +135,11 @@ k_vote(const float *__restrict__ disp, const short *__restrict__ binmap, const u
                 const size_t qrow = (size_t)p + (ptrdiff_t)(r0 - top) * W;    // first row of this chunk
                 uint32_t arow = 0;
                 if (lane < nr) arow = arms[qrow + (size_t)lane * W];
+                // settle the load here: otherwise every v_readlane of arow below is preceded by a full
+                // vmcnt(0), which also waits for the row loads just issued and serialises them
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(arow));
                 for (int t0 = 0; t0 < nr; t0 += VOTE_ROWS) {
-                    short ba[VOTE_ROWS], bb[VOTE_ROWS];
+                    int ba[VOTE_ROWS], bb[VOTE_ROWS];   // 32-bit: 16-bit values get packed in pairs, which serialises the loads
                     bool any_b = false;
 #pragma unroll
                     for (int u = 0; u < VOTE_ROWS; u++) {
