@@ -113,37 +113,41 @@ void launch_step_flags(const uint32_t *pix, uint8_t *flags, int W, int H, int ts
 
 // ---- cross arms -------------------------------------------------------------------------------
 // FindHorizontalArm / FindVerticalArm (ADC/cost_aggregator.cu:130-260) on the left image.
-__device__ __forceinline__ uint32_t find_arm(const uint32_t *__restrict__ pix, int W, int H, int x, int y,
-                                             int dx, int dy, uint32_t p0, int cap, int L2, int t1, int t2) {
-    uint32_t last = p0;
-    int xn = x + dx, yn = y + dy;
-    uint32_t arm = 0;
-    for (int n = 0; n < cap; n++) {
-        if (xn < 0 || xn >= W || yn < 0 || yn >= H) break;
-        const uint32_t p = pix[(size_t)yn * W + xn];
-        const int d1 = color_dist(p, p0);
-        if (d1 >= t1) break;
-        if (n > 0 && color_dist(p, last) >= t1) break;
-        if (n + 1 > L2 && d1 >= t2) break;
-        arm++;
-        last = p;
-        xn += dx;
-        yn += dy;
-    }
-    return arm;
-}
-
+// The four arms of a pixel are walked together, one step per iteration, so that four loads are in
+// flight instead of one dependent load per step. A walk stops (for good) at the image border, at a
+// pixel too far from the anchor (>= t1), too far from the previous pixel of the walk (>= t1, from the
+// second step on) or, beyond L2 pixels, not within t2 of the anchor.
 __global__ void __launch_bounds__(256) k_arms(const uint32_t *__restrict__ pix, uint32_t *__restrict__ arms,
                                               int W, int H, int cap, int L2, int t1, int t2) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= W || y >= H) return;
-    const uint32_t p0 = pix[(size_t)y * W + x];
-    const uint32_t l = find_arm(pix, W, H, x, y, -1, 0, p0, cap, L2, t1, t2);
-    const uint32_t r = find_arm(pix, W, H, x, y, +1, 0, p0, cap, L2, t1, t2);
-    const uint32_t t = find_arm(pix, W, H, x, y, 0, -1, p0, cap, L2, t1, t2);
-    const uint32_t b = find_arm(pix, W, H, x, y, 0, +1, p0, cap, L2, t1, t2);
-    arms[(size_t)y * W + x] = l | (r << 8) | (t << 16) | (b << 24);
+    const bool in = x < W && y < H;
+    const size_t i0 = in ? (size_t)y * W + x : 0;
+    const uint32_t p0 = pix[i0];
+    const int dx[4] = {-1, 1, 0, 0}, dy[4] = {0, 0, -1, 1};   // left, right, top, bottom (ADC/cross_aggregator.h:13)
+    uint32_t arm[4] = {0, 0, 0, 0}, last[4] = {p0, p0, p0, p0};
+    bool alive[4] = {in, in, in, in};
+    for (int n = 0; n < cap && __any(alive[0] | alive[1] | alive[2] | alive[3]); n++) {
+        uint32_t p[4];
+        bool inside[4];
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const int xn = x + (n + 1) * dx[d], yn = y + (n + 1) * dy[d];
+            inside[d] = alive[d] & ((unsigned)xn < (unsigned)W) & ((unsigned)yn < (unsigned)H);
+            p[d] = pix[inside[d] ? (size_t)yn * W + xn : i0];
+        }
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const int d1 = color_dist(p[d], p0);
+            bool go = inside[d] & (d1 < t1);
+            go &= (n == 0) | (color_dist(p[d], last[d]) < t1);
+            go &= (n + 1 <= L2) | (d1 < t2);
+            arm[d] += go;
+            last[d] = p[d];
+            alive[d] = go;
+        }
+    }
+    if (in) arms[i0] = arm[0] | (arm[1] << 8) | (arm[2] << 16) | (arm[3] << 24);
 }
 void launch_arms(const uint32_t *pix, uint32_t *arms, int W, int H, int L1, int L2, int t1, int t2, hipStream_t s) {
     const int cap = L1 < 255 ? L1 : 255;  // min(cross_L1, MAX_ARM_LENGTH), ADC/cost_aggregator.cu:145
