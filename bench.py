@@ -129,7 +129,7 @@ def main():
             "whole_match_roofline_frac": (72.0 * W * H * D + 120.0 * W * H) / (ms_per_frame * 1e-3) / (HBM_PEAK_GBS * 1e9),
             "stage_ms": {k: round(v, 4) for k, v in stage_acc.items()},
             "valid_fraction": valid_fraction,
-            "roofline": {"bound": "hbm", "kernel": "k_agg_ring (one cross-aggregation pass)",
+            "roofline": {"bound": "hbm", "kernel": "k_agg_pair (one cross-aggregation pass)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": agg_launch_ms},

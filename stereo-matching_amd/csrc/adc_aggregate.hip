@@ -261,10 +261,21 @@ __device__ __forceinline__ void range2(typename VecT<VEC>::T &a0, typename VecT<
 // end of the iteration: they are then older than exactly the two stores that follow them.
 // Ring: R >= 2*cap + 2*B slots (any number; slots are tracked as running counters, not by masking).
 #define PAIR_B (2 * AGG_WAVES)
-template <int VEC, bool DIV>
+// COST: the pass is the first one (horizontal, no division) and its input is not read from a volume but
+// computed on the spot: ComputeCostCuda's expression (ADC/cost_computor.cu:151-207)
+//     ((1 - e_ad[sum|dBGR|]) + 1) - e_cen[popcount(cenL ^ cenR)],   1.0f where x-d is outside the image,
+// evaluated per ring slot from the right row's {pixel, census} entries and the two exp tables staged in
+// LDS. The initial cost volume then never exists in HBM (one volume write and one volume read less).
+struct CostSrc {
+    const uint32_t *pix_l, *pix_r, *cen_l, *cen_r;
+    const float *lut_ad, *lut_cen;
+    int dmin, D;
+};
+template <int VEC, bool DIV, bool COST>
 __global__ void __launch_bounds__(AGG_WAVES * 64)
 k_agg_pair(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ arms,
-           const uint32_t *__restrict__ cnt, int W, int H, int Dp, int vertical, int seglen, int cap, int R) {
+           const uint32_t *__restrict__ cnt, int W, int H, int Dp, int vertical, int seglen, int cap, int R,
+           CostSrc cs) {
     typedef typename VecT<VEC>::T vec_t;
     constexpr int SLOT = 64 * VEC;
     constexpr int B = PAIR_B;
@@ -290,17 +301,62 @@ k_agg_pair(const float *__restrict__ src, float *__restrict__ dst, const uint32_
     const bool kok = kc + lane * VEC < Dp;
     const float *rl = ring + lane * VEC;
 
+    // COST: right-row entries any (position, disparity) pair of this segment and chunk can touch, i.e.
+    // columns xr_base .. xr_base + nr - 1 with xr = p - dmin - k, and the two exp tables
+    uint2 *s_r = reinterpret_cast<uint2 *>(ring + (size_t)R * SLOT);
+    const int nr = COST ? (in_hi - in_lo) + SLOT - 1 : 0;
+    float *s_ad = reinterpret_cast<float *>(s_r + nr);     // 766 (+2)
+    float *s_cen = s_ad + 768;                             // 65 (+3)
+    const int xr_base = in_lo - cs.dmin - kc - (SLOT - 1);
+    if (COST) {
+        for (int i = threadIdx.x; i < nr; i += AGG_WAVES * 64) {
+            const int xr = xr_base + i;
+            uint2 v = make_uint2(0u, 0u);
+            if (xr >= 0 && xr < W) {
+                const size_t q = (size_t)line * W + xr;
+                v = make_uint2(cs.pix_r[q], cs.cen_r[q]);
+            }
+            s_r[i] = v;
+        }
+        for (int i = threadIdx.x; i < 766; i += AGG_WAVES * 64) s_ad[i] = cs.lut_ad[i];
+        if (threadIdx.x < 65) s_cen[threadIdx.x] = cs.lut_cen[threadIdx.x];
+        __syncthreads();
+    }
+    // costs of position p (a column of row `line`) for this chunk's disparities into ring slot q
+    auto cost_fill = [&](int p, int q) {
+        const size_t pi = (size_t)line * W + p;
+        const uint32_t pl = cs.pix_l[pi], cl = cs.cen_l[pi];
+#pragma unroll
+        for (int h = 0; h < VEC; h++) {
+            const int jj = h * 64 + lane;                  // disparity index inside the chunk = float inside the slot
+            const int xr = p - cs.dmin - kc - jj;
+            float c = 1.0f;
+            if (xr >= 0 && xr < W) {
+                const uint2 r = s_r[xr - xr_base];
+                const uint32_t sad = __builtin_amdgcn_sad_u8(pl, r.x, 0u);
+                const uint32_t ham = __builtin_popcount(cl ^ r.y);
+                c = ((1.0f - s_ad[sad]) + 1.0f) - s_cen[ham];
+            }
+            if (kc + jj >= cs.D) c = 0.0f;                 // padding past D holds zeros, as the volume does
+            ring[q * SLOT + jj] = c;
+        }
+    };
+
     // prologue: input position in_lo + j lands in slot j; everything block 0 reads
     {
         const int pro_n = min(in_hi, s0 + B + cap) - in_lo;     // <= R - B
-        const float *g = fsrc + (size_t)(in_lo + wave) * mstride;
-        for (int j = wave; j < pro_n; j += AGG_WAVES, g += (ptrdiff_t)AGG_WAVES * mstride) {
+        if (COST) {
+            for (int j = wave; j < pro_n; j += AGG_WAVES) cost_fill(in_lo + j, j);
+        } else {
+            const float *g = fsrc + (size_t)(in_lo + wave) * mstride;
+            for (int j = wave; j < pro_n; j += AGG_WAVES, g += (ptrdiff_t)AGG_WAVES * mstride) {
 #pragma unroll
-            for (int h = 0; h < VEC; h++)
-                if (fok[h]) ring_fill(g + h * 64, ring + j * SLOT + h * 64);
+                for (int h = 0; h < VEC; h++)
+                    if (fok[h]) ring_fill(g + h * 64, ring + j * SLOT + h * 64);
+            }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
     int o = s0 + 2 * wave;                        // first of this wave's two positions
@@ -331,9 +387,13 @@ k_agg_pair(const float *__restrict__ src, float *__restrict__ dst, const uint32_
             if (n0 + 2 * wave + j < in_hi) {
                 int q = qf + j;
                 if (q >= R) q -= R;
+                if (COST) {
+                    cost_fill(n0 + 2 * wave + j, q);
+                } else {
 #pragma unroll
-                for (int h = 0; h < VEC; h++)
-                    if (fok[h]) ring_fill(fill_p + (ptrdiff_t)j * mstride + h * 64, ring + q * SLOT + h * 64);
+                    for (int h = 0; h < VEC; h++)
+                        if (fok[h]) ring_fill(fill_p + (ptrdiff_t)j * mstride + h * 64, ring + q * SLOT + h * 64);
+                }
             }
         }
         uint32_t a_nxt[2] = {0u, 0u}, c_nxt[2] = {1u, 1u};
@@ -375,7 +435,7 @@ k_agg_pair(const float *__restrict__ src, float *__restrict__ dst, const uint32_
         for (int j = 0; j < 2; j++) { a_cur[j] = a_nxt[j]; c_cur[j] = c_nxt[j]; }
         // (c) the next block's fills must have landed before anyone reads them. Once a fill has been
         //     skipped (end of the line / segment) no further fill follows: drain once, then stop waiting.
-        if (fills_live) {
+        if (!COST && fills_live) {            // (COST: the ring is written by ds_write, ordered by the wait below)
             if (n0 + B > in_hi) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 fills_live = false;
@@ -460,31 +520,65 @@ static void launch_ring(const float *src, float *dst, const uint32_t *arms, cons
 
 template <int VEC>
 static void launch_pair(const float *src, float *dst, const uint32_t *arms, const uint32_t *cnt, const Geom &g,
-                        int vertical, int max_arm, hipStream_t s) {
+                        int vertical, int max_arm, const CostSrc *cost, hipStream_t s) {
     const int SLOT = 64 * VEC;
     const int chunks = (g.Dp + SLOT - 1) / SLOT;
     const int lines = vertical ? g.W : g.H;
     const int LEN = vertical ? g.H : g.W;
     const int R = 2 * max_arm + 2 * PAIR_B;
-    const size_t lds = (size_t)R * SLOT * sizeof(float);
+    size_t lds = (size_t)R * SLOT * sizeof(float);
     int nseg = 1;
     const long long wgs = (long long)chunks * lines;
     if (wgs < 4096) nseg = (int)((4096 + wgs - 1) / wgs);
     int seglen = (LEN + nseg - 1) / nseg;
     seglen = ((seglen + PAIR_B - 1) / PAIR_B) * PAIR_B;
     if (seglen < 128) seglen = 128;
+    if (cost) {
+        // the staged right-row entries (seglen + 2*cap + SLOT - 1 of 8 B) and the exp tables share the 80 KB
+        const long long room = (80 * 1024 - (long long)lds - 836 * 4) / 8 - 2 * max_arm - (SLOT - 1);
+        const int max_seg = (int)(room / PAIR_B) * PAIR_B;
+        if (seglen > max_seg) seglen = max_seg;
+        lds += (size_t)(seglen + 2 * max_arm + SLOT - 1) * 8 + 836 * 4;
+    }
     nseg = (LEN + seglen - 1) / seglen;
     dim3 grid(chunks, lines, nseg), block(AGG_WAVES * 64);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_agg_pair<VEC, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_agg_pair<VEC, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_agg_pair<VEC, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_agg_pair<VEC, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_agg_pair<VEC, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         attr_set = true;
     }
-    if (cnt)
-        k_agg_pair<VEC, true><<<grid, block, lds, s>>>(src, dst, arms, cnt, g.W, g.H, g.Dp, vertical, seglen, max_arm, R);
+    const CostSrc none = {};
+    if (cost)
+        k_agg_pair<VEC, false, true><<<grid, block, lds, s>>>(src, dst, arms, cnt, g.W, g.H, g.Dp, vertical, seglen, max_arm, R, *cost);
+    else if (cnt)
+        k_agg_pair<VEC, true, false><<<grid, block, lds, s>>>(src, dst, arms, cnt, g.W, g.H, g.Dp, vertical, seglen, max_arm, R, none);
     else
-        k_agg_pair<VEC, false><<<grid, block, lds, s>>>(src, dst, arms, cnt, g.W, g.H, g.Dp, vertical, seglen, max_arm, R);
+        k_agg_pair<VEC, false, false><<<grid, block, lds, s>>>(src, dst, arms, cnt, g.W, g.H, g.Dp, vertical, seglen, max_arm, R, none);
+}
+
+static bool pair_kernel_ok(const Geom &g, int max_arm) {
+    static const int pair_env = std::getenv("ADC_AGG_PAIR") ? std::atoi(std::getenv("ADC_AGG_PAIR")) : 1;
+    const int vec = (g.Dp >= 128 && g.Dp % 2 == 0) ? 2 : 1;
+    return pair_env && (long long)g.W * g.Dp * (PAIR_B + 2) < (1ll << 31) &&
+           (size_t)(2 * max_arm + 2 * PAIR_B) * 64 * vec * 4 <= 80 * 1024;
+}
+
+// The first aggregation pass (horizontal, no division) with the initial costs computed inside it.
+bool aggregate_cost_fusion_supported(const Geom &g, int max_arm) {
+    static const int env = std::getenv("ADC_COST_FUSE") ? std::atoi(std::getenv("ADC_COST_FUSE")) : 1;
+    const int vec = (g.Dp >= 128 && g.Dp % 2 == 0) ? 2 : 1;
+    // room for at least a 128-position segment of right-row entries next to the ring and the tables
+    const long long room = (80 * 1024 - (long long)(2 * max_arm + 2 * PAIR_B) * 64 * vec * 4 - 836 * 4) / 8 - 2 * max_arm - (64 * vec - 1);
+    return env && pair_kernel_ok(g, max_arm) && room >= 128;
+}
+void launch_aggregate_first_pass_with_cost(const Planes &p, const float *lut_ad, const float *lut_cen, float *dst,
+                                           const Geom &g, int max_arm, hipStream_t s) {
+    const CostSrc cs = {p.pix_l, p.pix_r, p.cen_l, p.cen_r, lut_ad, lut_cen, g.dmin, g.D};
+    const int vec = (g.Dp >= 128 && g.Dp % 2 == 0) ? 2 : 1;
+    if (vec == 2) launch_pair<2>(nullptr, dst, p.arms, nullptr, g, 0, max_arm, &cs, s);
+    else launch_pair<1>(nullptr, dst, p.arms, nullptr, g, 0, max_arm, &cs, s);
 }
 
 void launch_aggregate_pass(const float *src, float *dst, const uint32_t *arms, const uint32_t *cnt,
@@ -501,12 +595,9 @@ void launch_aggregate_pass(const float *src, float *dst, const uint32_t *arms, c
         if ((size_t)r * 64 * vec * 4 <= 64 * 1024) { depth = d; R = r; break; }
     }
     // two positions per wave when its ring (2*cap + 64 slots) leaves room for two workgroups per CU
-    static const int pair_env = std::getenv("ADC_AGG_PAIR") ? std::atoi(std::getenv("ADC_AGG_PAIR")) : 1;
-    const bool pair_ok = (long long)g.W * g.Dp * (PAIR_B + 2) < (1ll << 31) &&
-                         (size_t)(2 * max_arm + 2 * PAIR_B) * 64 * vec * 4 <= 80 * 1024;
-    if (variant == 0 && pair_env && pair_ok) {
-        if (vec == 2) launch_pair<2>(src, dst, arms, cnt, g, vertical, max_arm, s);
-        else launch_pair<1>(src, dst, arms, cnt, g, vertical, max_arm, s);
+    if (variant == 0 && pair_kernel_ok(g, max_arm)) {
+        if (vec == 2) launch_pair<2>(src, dst, arms, cnt, g, vertical, max_arm, nullptr, s);
+        else launch_pair<1>(src, dst, arms, cnt, g, vertical, max_arm, nullptr, s);
     } else if (variant == 0 && strides_ok && depth) {
 #define ADC_RING(V, D) launch_ring<V, D>(src, dst, arms, cnt, g, vertical, max_arm, R, s)
         if (vec == 2) { if (depth == 6) ADC_RING(2, 6); else if (depth == 4) ADC_RING(2, 4); else ADC_RING(2, 2); }

@@ -285,16 +285,22 @@ int enqueue_match(adc_handle *h, const uint8_t *d_l, const uint8_t *d_r, float *
     launch_sup_counts(pl.arms, pl.cnt_h, pl.cnt_v, pl.cnt_h32, pl.cnt_v32, g.W, g.H, s);
     launch_scan_records(pl, g, s);
 
+    // The initial cost volume is computed inside the first aggregation pass when that is possible; it is
+    // materialised (ComputeCostCuda as a kernel of its own) when its tap is wanted or the pass cannot hold it.
+    const int cap = max_arm_of(o);
+    const bool fuse_cost = !h->debug_taps && h->agg_variant == 0 && aggregate_cost_fusion_supported(g, cap);
     mark(ADC_STAGE_COST);
-    launch_cost_init(pl, g, h->lut_ad, h->lut_cen, h->vol_b, s);
+    if (!fuse_cost) launch_cost_init(pl, g, h->lut_ad, h->lut_cen, h->vol_b, s);
     snap(h->snap_init, h->vol_b, nvol * sizeof(float));
 
     // CrossAggregator::Aggregate: 4 iterations, horizontal-first on even ones (ADC/cost_aggregator.cu:112,440-454)
     mark(ADC_STAGE_AGGR);
-    const int cap = max_arm_of(o);
     for (int it = 0; it < 4; it++) {
         const bool hfirst = (it % 2) == 0;
-        launch_aggregate_pass(h->vol_b, h->vol_a, pl.arms, nullptr, g, hfirst ? 0 : 1, cap, h->agg_variant, s);
+        if (it == 0 && fuse_cost)
+            launch_aggregate_first_pass_with_cost(pl, h->lut_ad, h->lut_cen, h->vol_a, g, cap, s);
+        else
+            launch_aggregate_pass(h->vol_b, h->vol_a, pl.arms, nullptr, g, hfirst ? 0 : 1, cap, h->agg_variant, s);
         launch_aggregate_pass(h->vol_a, h->vol_b, pl.arms, hfirst ? pl.cnt_h32 : pl.cnt_v32, g, hfirst ? 1 : 0, cap,
                               h->agg_variant, s);
     }

@@ -52,6 +52,11 @@ void launch_census_to_u64(const uint32_t *c32, uint64_t *c64, size_t n, hipStrea
 // variant: 0 = ring kernel (LDS), 1 = direct-global fallback.
 void launch_aggregate_pass(const float *src, float *dst, const uint32_t *arms, const uint32_t *cnt,
                            const Geom &g, int vertical, int max_arm, int variant, hipStream_t s);
+// The first pass (horizontal, no division) with the initial cost volume computed inside the kernel
+// instead of being read: only when aggregate_cost_fusion_supported().
+bool aggregate_cost_fusion_supported(const Geom &g, int max_arm);
+void launch_aggregate_first_pass_with_cost(const Planes &p, const float *lut_ad, const float *lut_cen, float *dst,
+                                           const Geom &g, int max_arm, hipStream_t s);
 
 // --- adc_scanline.hip --------------------------------------------------------------------------
 // One directional scanline pass (src -> dst). Ptab = {P1[0..2], P2[0..2]} indexed by how many of

@@ -129,6 +129,23 @@ def test_tiny_images(pkg, orc):
         check_against_oracle(pkg, orc, L, R, max_disparity=5)
 
 
+@pytest.mark.parametrize("seed,W,H,dmin,dmax", [(51, 203, 117, 0, 48), (52, 230, 150, 3, 133), (53, 150, 40, 0, 300),
+                                                 (54, 700, 64, -4, 60), (55, 5, 3, 0, 5)])
+def test_cost_fused_first_pass(pkg, orc, synth, seed, W, H, dmin, dmax):
+    """Without the debug taps the initial costs are computed inside the first aggregation pass; the final
+    scanline volume and the final map (both readable without taps) must still be the oracle's bits."""
+    L, R, _ = synth.pair(seed, max(W, 16), max(H, 16), max(dmax - dmin, 8))
+    L, R = np.ascontiguousarray(L[:H, :W]), np.ascontiguousarray(R[:H, :W])
+    h = pkg.ADCensusStereo(0)
+    assert h.Initialize(W, H, pkg.ADCensusOption(min_disparity=dmin, max_disparity=dmax)), h.last_error()
+    disp = h.match(L, R)
+    vol = h.get_buffer("cost_scan")
+    h.close()
+    want, taps = orc.match(L, R, orc.default_option(min_disparity=dmin, max_disparity=dmax), want=["cost_scan"])
+    assert same(vol, taps["cost_scan"]), describe("cost_scan", vol, taps["cost_scan"])
+    assert same(disp, want), describe("disp_final", disp, want)
+
+
 def test_direct_aggregation_kernel(pkg, orc, synth, monkeypatch):
     monkeypatch.setenv("ADC_AGG_VARIANT", "1")
     L, R, _ = synth.pair(23, 170, 90, 70)
