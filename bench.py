@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--disp", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="multi-rank rehearsal on a one-GPU box: gloo backend, every rank on device 0")
     args = ap.parse_args()
 
     import torch
@@ -53,10 +55,15 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29500")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the matcher has no CPU fallback")
+    if args.rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     pkg = importlib.import_module("stereo-matching_amd")
     synth = importlib.import_module("stereo-matching_amd.synth")
@@ -78,7 +85,7 @@ def main():
 
     batch = importlib.import_module("stereo-matching_amd.batch")
     elapsed = batch.timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize,
-                                dist if world > 1 else None, dev)
+                                dist if world > 1 else None, None if args.rehearse else dev)
 
     valid_fraction = float(torch.isfinite(d_out).float().mean().item())
 
