@@ -256,6 +256,29 @@ __device__ __forceinline__ void range2(typename VecT<VEC>::T &a0, typename VecT<
     if (n > n1) span2<VEC>(a0, a1, rl, 0, n - n1);
 }
 
+// a / c, correctly rounded (the same bits as the IEEE division the reference does), for a sum a >= 0 that
+// is zero or a normal number and a support count c that is an integer in [1, 2^14]:
+//     q0 = a * rcp(c);   e = fma(-c, q0, a);   q = fma(e, rcp(c), q0)
+// q0 is within two ulps, so the remainder e = a - c*q0 is a small multiple of ulp(q0) and exact; e*rcp(c)
+// misses e/c by less than 2^-22 ulp, while a/c keeps at least ulp/(2c) >= 2^-15 ulp away from every
+// rounding boundary (a/c cannot be a midpoint between two floats for an integer c). Three instructions
+// per value instead of the scale / refine / fix-up sequence of a general division.
+template <int VEC>
+__device__ __forceinline__ typename VecT<VEC>::T div_by_count(typename VecT<VEC>::T a, float c) {
+    const float r = __builtin_amdgcn_rcpf(c);
+    if constexpr (VEC == 1) {
+        const float q0 = a * r;
+        const float e = __builtin_fmaf(-c, q0, a);
+        return __builtin_fmaf(e, r, q0);
+    } else {
+        typedef typename VecT<VEC>::T vec_t;
+        const vec_t rv = {r, r}, nc = {-c, -c};
+        const vec_t q0 = a * rv;
+        const vec_t e = __builtin_elementwise_fma(nc, q0, a);
+        return __builtin_elementwise_fma(e, rv, q0);
+    }
+}
+
 // Workgroup iteration i: wave w produces positions o0 + 2w and o0 + 2w + 1 (B = 32 per iteration);
 // the fills of the block iteration i+1 adds to the window are issued first and must have landed by the
 // end of the iteration: they are then older than exactly the two stores that follow them.
@@ -423,8 +446,8 @@ k_agg_pair(const float *__restrict__ src, float *__restrict__ dst, const uint32_
             if (e0 > e1) { const int t = max(b0, e1 + 1); range1<VEC>(acc0, rl, t, e0 - t + 1, R); }
             else if (e1 > e0) { const int t = max(b1, e0 + 1); range1<VEC>(acc1, rl, t, e1 - t + 1, R); }
             if (DIV) {
-                acc0 = acc0 / (float)c_cur[0];
-                acc1 = acc1 / (float)c_cur[1];
+                acc0 = div_by_count<VEC>(acc0, (float)c_cur[0]);
+                acc1 = div_by_count<VEC>(acc1, (float)c_cur[1]);
             }
             if (kok) {
                 *reinterpret_cast<vec_t *>(out_p) = acc0;

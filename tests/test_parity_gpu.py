@@ -146,6 +146,21 @@ def test_cost_fused_first_pass(pkg, orc, synth, seed, W, H, dmin, dmax):
     assert same(disp, want), describe("disp_final", disp, want)
 
 
+def test_aggregated_volume_midsize(pkg, orc, synth):
+    """640x360x256: the aggregated and the final cost volume bit for bit (about a quarter of a billion
+    support-count divisions and as many scanline updates against the CPU's)."""
+    L, R, _ = synth.pair(71, 640, 360, 256)
+    h = pkg.ADCensusStereo(0)
+    h.set_debug_taps(True)
+    assert h.Initialize(640, 360, pkg.ADCensusOption(max_disparity=256)), h.last_error()
+    h.match(L, R)
+    got = {k: h.get_buffer(k) for k in ("cost_aggr", "cost_scan")}
+    h.close()
+    _, want = orc.match(L, R, orc.default_option(max_disparity=256), want=["cost_aggr", "cost_scan"])
+    for k in ("cost_aggr", "cost_scan"):
+        assert same(got[k], want[k]), describe(k, got[k], want[k])
+
+
 def test_direct_aggregation_kernel(pkg, orc, synth, monkeypatch):
     monkeypatch.setenv("ADC_AGG_VARIANT", "1")
     L, R, _ = synth.pair(23, 170, 90, 70)
