@@ -110,7 +110,7 @@ def main():
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         if tj["workload"] == {"width": W, "height": H, "disparities": D}:
-            traffic = tj["k_agg_ring"]["hbm_bytes_per_launch"]
+            traffic = tj["aggregation_pass"]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
 

@@ -12,11 +12,17 @@
 // lane adds its span in ascending t starting from 0.0f -- the reference's order
 // (ADC/cost_aggregator.cu:346-372), so the sums are bit-identical to a sequential CPU evaluation.
 //
-// Ring kernel: a 512-thread workgroup (8 waves) owns one scanline (a row for horizontal passes, a
-// column for vertical ones) x 64*VEC disparities and marches along it, 8 output positions per
-// iteration (one per wave). The input positions any in-flight block can touch live in an LDS ring
-// [R][64*VEC] floats, so each input element is fetched from HBM once per pass and re-read up to
-// 2*cap+1 times from LDS (lane l reads floats l*VEC.. of a slot: conflict-free ds_read_b32/b64).
+// Ring kernels: a 1024-thread workgroup (16 waves) owns one scanline (a row for horizontal passes, a
+// column for vertical ones) x 64*VEC disparities and marches along it. The input positions any
+// in-flight block can touch live in an LDS ring of slots of 64*VEC floats filled by LDS-DMA, so each
+// input element is fetched from HBM once per pass and re-read up to 2*cap+1 times from LDS (lane l
+// reads floats l*VEC.. of a slot: conflict-free ds_read_b32/b64).
+//   k_agg_pair   two adjacent positions per wave share their ring reads; used whenever its ring fits
+//                twice into a CU's LDS; optionally computes the initial costs itself (first pass)
+//   k_agg_ring   one position per wave (power-of-two ring), kept for arm caps k_agg_pair cannot hold
+//   k_agg_direct no LDS, any arm cap
+// The ring kernels are bound by instruction issue and by the ~5.2 TB/s a mixed read+write stream gets
+// from HBM, not by LDS bandwidth.
 #include "adc_common.h"
 
 #include <cstdlib>
