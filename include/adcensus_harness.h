@@ -37,6 +37,31 @@ int adc_disparity_to_u8(const float *disp, int width, int height, uint8_t *out);
 int adc_eval_0103(const float *disp, const uint8_t *gt, int width, int height, float gt_div, float delta,
                   double seconds, float *rms, float *pep, float *mde);
 
+/* Single-channel little-endian PFM ("Pf"), rows stored bottom-up, as LoadPFM / savePFM handle the
+ * Middlebury 2021 ground truth (ADC/performance_eval.cpp:11-181). *data: float[height][width], top row
+ * first, allocated by the library (release with adc_float_free). Colour ("PF") files are rejected. */
+int adc_pfm_read(const char *path, float **data, int *width, int *height);
+void adc_float_free(float *data);
+int adc_pfm_write(const char *path, const float *data, int width, int height);
+
+/* PerformanceEval (ADC/performance_eval.cpp:184-215), the 2021 evaluation against a PFM ground truth:
+ * every pixel counts, an unknown (+inf) ground truth counts as disparity 0, error = estimate - truth (an
+ * invalid estimate makes RMS infinite, as in the reference), PEP = fraction with |error| > delta,
+ * Mde = width*height*max(estimate)*1e-6 / seconds. float32 accumulation in row-major order. */
+int adc_eval_pfm(const float *disp, const float *gt, int width, int height, float delta, double seconds,
+                 float *rms, float *pep, float *mde);
+
+/* Disp2Depth2 (ADC/main.cpp:499-551): depth = focal*baseline/|d| + doffs where d is valid and non-zero,
+ * 0 elsewhere; min / max over the whole map (starting from 114514 / 0, so any zero pulls the minimum to 0);
+ * depth_u8 = (uchar)((depth - min) / (max - min) * 255), all zeros when max == min. depth and depth_u8 may
+ * each be NULL. The reference takes focal and baseline from tables that repeat the calib.txt files
+ * (ADC/main.cpp:9-20) and doffs = 0. */
+int adc_disparity_to_depth(const float *disp, int width, int height, float focal, float baseline, float doffs,
+                           float *depth, uint8_t *depth_u8, float *min_depth, float *max_depth);
+
+/* focal length (cam0[0][0]), baseline and doffs of a Middlebury 2021 calib.txt. */
+int adc_calib_read(const char *path, float *focal, float *baseline, float *doffs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,7 +81,9 @@ EXPORTS = [
     "adc_aggr_kernel_stats", "adc_buffer_bytes", "adc_get_buffer", "adc_match_batch", "adc_last_error",
 ]
 # ... and include/adcensus_harness.h
-HARNESS_EXPORTS = ["adc_png_read", "adc_image_free", "adc_png_write_gray", "adc_disparity_to_u8", "adc_eval_0103"]
+HARNESS_EXPORTS = ["adc_png_read", "adc_image_free", "adc_png_write_gray", "adc_disparity_to_u8", "adc_eval_0103",
+                   "adc_pfm_read", "adc_float_free", "adc_pfm_write", "adc_eval_pfm", "adc_disparity_to_depth",
+                   "adc_calib_read"]
 
 _lib = None
 
@@ -122,6 +124,15 @@ def lib():
         L.adc_disparity_to_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.adc_eval_0103.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_double,
                                     C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.adc_pfm_read.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.adc_float_free.restype = None
+        L.adc_float_free.argtypes = [C.c_void_p]
+        L.adc_pfm_write.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
+        L.adc_eval_pfm.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_double,
+                                   C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.adc_disparity_to_depth.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                                             C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.adc_calib_read.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
         _lib = L
     return _lib
 
@@ -290,3 +301,53 @@ def eval_0103(disp, gt_u8, gt_div=4.0, delta=2.0, seconds=1.0):
                              C.byref(rms), C.byref(pep), C.byref(mde))
     assert rc == 0
     return rms.value, pep.value, mde.value
+
+
+def pfm_read(path):
+    """Single-channel little-endian PFM -> f32[H][W], top row first (LoadPFM, performance_eval.cpp:11-91)."""
+    p, w, h = C.c_void_p(), C.c_int(), C.c_int()
+    rc = lib().adc_pfm_read(os.fsencode(path), C.byref(p), C.byref(w), C.byref(h))
+    if rc != 0:
+        raise IOError("adc_pfm_read(%s) failed (%d)" % (path, rc))
+    a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(h.value, w.value)).copy()
+    lib().adc_float_free(p)
+    return a
+
+
+def pfm_write(path, data):
+    d = np.ascontiguousarray(data, np.float32)
+    rc = lib().adc_pfm_write(os.fsencode(path), d.ctypes.data, d.shape[1], d.shape[0])
+    if rc != 0:
+        raise IOError("adc_pfm_write(%s) failed (%d)" % (path, rc))
+
+
+def eval_pfm(disp, gt, delta=2.0, seconds=1.0):
+    """The reference's PerformanceEval against a PFM ground truth (performance_eval.cpp:184-215)."""
+    d = np.ascontiguousarray(disp, np.float32)
+    g = np.ascontiguousarray(gt, np.float32)
+    assert d.shape == g.shape
+    rms, pep, mde = C.c_float(), C.c_float(), C.c_float()
+    rc = lib().adc_eval_pfm(d.ctypes.data, g.ctypes.data, d.shape[1], d.shape[0], delta, seconds,
+                            C.byref(rms), C.byref(pep), C.byref(mde))
+    assert rc == 0
+    return rms.value, pep.value, mde.value
+
+
+def disparity_to_depth(disp, focal, baseline, doffs=0.0):
+    """The reference's Disp2Depth2 (main.cpp:499-551): (depth f32, depth u8, min, max)."""
+    d = np.ascontiguousarray(disp, np.float32)
+    depth = np.empty(d.shape, np.float32)
+    u8 = np.empty(d.shape, np.uint8)
+    lo, hi = C.c_float(), C.c_float()
+    rc = lib().adc_disparity_to_depth(d.ctypes.data, d.shape[1], d.shape[0], focal, baseline, doffs,
+                                      depth.ctypes.data, u8.ctypes.data, C.byref(lo), C.byref(hi))
+    assert rc == 0
+    return depth, u8, lo.value, hi.value
+
+
+def calib_read(path):
+    f, b, o = C.c_float(), C.c_float(), C.c_float()
+    rc = lib().adc_calib_read(os.fsencode(path), C.byref(f), C.byref(b), C.byref(o))
+    if rc != 0:
+        raise IOError("adc_calib_read(%s) failed (%d)" % (path, rc))
+    return f.value, b.value, o.value

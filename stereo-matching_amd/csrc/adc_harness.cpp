@@ -9,7 +9,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cctype>
 #include <limits>
+#include <string>
 #include <vector>
 
 namespace {
@@ -203,6 +205,126 @@ int adc_eval_0103(const float *disp, const uint8_t *gt, int width, int height, f
     if (rms) *rms = std::sqrt(sq / (float)(height * width));
     if (pep) *pep = bad / (float)(height * width);
     if (mde) *mde = (float)((double)((float)(width * height) * dmax) / seconds * 1e-6);
+    return 0;
+}
+
+int adc_pfm_read(const char *path, float **data, int *width, int *height) {
+    if (!path || !data || !width || !height) return 1;
+    std::vector<uint8_t> f;
+    if (!read_file(path, f)) return 2;
+    // header: "Pf\n<width> <height>\n<scale>\n"; a negative scale means little endian
+    size_t p = 0;
+    auto token = [&](std::string &t) {
+        t.clear();
+        while (p < f.size() && std::isspace(f[p])) p++;
+        while (p < f.size() && !std::isspace(f[p])) t.push_back((char)f[p++]);
+        return !t.empty();
+    };
+    std::string t;
+    if (!token(t) || t != "Pf") return t == "PF" ? 4 : 3;
+    int W = 0, H = 0;
+    if (!token(t)) return 3;
+    W = std::atoi(t.c_str());
+    if (!token(t)) return 3;
+    H = std::atoi(t.c_str());
+    if (!token(t)) return 3;
+    const double scale = std::atof(t.c_str());
+    if (W <= 0 || H <= 0 || W > 65535 || H > 65535 || !(scale < 0)) return 4;   // big-endian files: not supported
+    p++;                                                                       // the single whitespace after the scale
+    const size_t n = (size_t)W * H;
+    if (f.size() < p + n * 4) return 5;
+    float *out = (float *)std::malloc(n * sizeof(float));
+    if (!out) return 6;
+    for (int y = 0; y < H; y++)   // the file's first row is the image's bottom row
+        std::memcpy(out + (size_t)(H - 1 - y) * W, f.data() + p + (size_t)y * W * 4, (size_t)W * 4);
+    *data = out;
+    *width = W;
+    *height = H;
+    return 0;
+}
+
+void adc_float_free(float *data) { std::free(data); }
+
+int adc_pfm_write(const char *path, const float *data, int width, int height) {
+    if (!path || !data || width <= 0 || height <= 0) return 1;
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return 2;
+    std::fprintf(f, "Pf\n%d %d\n-1.000000\n", width, height);   // ADC/performance_eval.cpp:120-140
+    bool ok = true;
+    for (int y = height - 1; y >= 0 && ok; y--)
+        ok = std::fwrite(data + (size_t)y * width, sizeof(float), (size_t)width, f) == (size_t)width;
+    std::fclose(f);
+    return ok ? 0 : 2;
+}
+
+int adc_eval_pfm(const float *disp, const float *gt, int width, int height, float delta, double seconds,
+                 float *rms, float *pep, float *mde) {
+    if (!disp || !gt || width <= 0 || height <= 0) return 1;
+    const float inf = std::numeric_limits<float>::infinity();
+    float sq = 0.0f, bad = 0.0f, dmax = 0.0f;
+    for (int y = 0; y < height; y++) {
+        for (int x = 0; x < width; x++) {
+            const size_t i = (size_t)y * width + x;
+            dmax = dmax > disp[i] ? dmax : disp[i];
+            const float g = gt[i] == inf ? 0.0f : gt[i];
+            const float d = disp[i] - g;
+            sq += d * d;
+            bad += (std::fabs(d) > delta);
+        }
+    }
+    if (rms) *rms = std::sqrt(sq / (float)(height * width));
+    if (pep) *pep = bad / (float)(height * width);
+    if (mde) *mde = (float)((double)((float)(width * height) * dmax) * 1e-6 / seconds);
+    return 0;
+}
+
+int adc_disparity_to_depth(const float *disp, int width, int height, float focal, float baseline, float doffs,
+                           float *depth, uint8_t *depth_u8, float *min_depth, float *max_depth) {
+    if (!disp || width <= 0 || height <= 0) return 1;
+    const float inf = std::numeric_limits<float>::infinity();
+    const size_t n = (size_t)width * height;
+    std::vector<float> tmp;
+    if (!depth) { tmp.resize(n); depth = tmp.data(); }
+    float lo = 114514.0f, hi = 0.0f;                       // ADC/main.cpp:516-517
+    for (size_t i = 0; i < n; i++) {
+        float d = std::fabs(disp[i]);
+        if (d == inf) d = 0;
+        depth[i] = d == 0 ? 0.0f : (float)(focal * baseline / d + doffs);
+    }
+    for (size_t i = 0; i < n; i++) {
+        const float z = std::fabs(depth[i]);
+        if (z != inf) {
+            lo = z < lo ? z : lo;
+            hi = z > hi ? z : hi;
+        }
+    }
+    if (depth_u8) {
+        const float span = hi - lo;
+        for (size_t i = 0; i < n; i++) {
+            const float z = std::fabs(depth[i]);
+            depth_u8[i] = (z == inf || !(span > 0.0f)) ? 0 : (uint8_t)((z - lo) / span * 255);
+        }
+    }
+    if (min_depth) *min_depth = lo;
+    if (max_depth) *max_depth = hi;
+    return 0;
+}
+
+int adc_calib_read(const char *path, float *focal, float *baseline, float *doffs) {
+    if (!path) return 1;
+    std::vector<uint8_t> f;
+    if (!read_file(path, f)) return 2;
+    const std::string txt(f.begin(), f.end());
+    auto value = [&](const char *key, float *out) {
+        const size_t at = txt.find(key);
+        if (at == std::string::npos) return false;
+        size_t p = at + std::strlen(key);
+        while (p < txt.size() && (txt[p] == '[' || txt[p] == ' ')) p++;
+        if (out) *out = (float)std::atof(txt.c_str() + p);
+        return true;
+    };
+    if (!value("cam0=", focal) || !value("baseline=", baseline)) return 3;
+    if (!value("doffs=", doffs) && doffs) *doffs = 0.0f;
     return 0;
 }
 

@@ -4,7 +4,9 @@
 // print the evaluation block of PerformanceEval0103.
 //
 //   adc_match LEFT.png RIGHT.png OUT.png [--min N] [--max N] [--gt GT.png] [--gt-div F] [--delta F]
-//             [--raw OUT.f32] [--device N]
+//             [--gt-pfm GT.pfm] [--calib calib.txt --depth DEPTH.png] [--raw OUT.f32] [--device N]
+// --gt-pfm: the 2021 evaluation (PerformanceEval, ADC/performance_eval.cpp:184-215);
+// --calib/--depth: Disp2Depth2 (ADC/main.cpp:499-551) with focal length and baseline from the scene's calib.txt.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -22,7 +24,7 @@ int main(int argc, char **argv) {
         return 2;
     }
     ADCensusOption opt;               // defaults of ADC/adcensus_types.h:86-93
-    std::string gt_path, raw_path;
+    std::string gt_path, raw_path, gt_pfm, calib_path, depth_path;
     float gt_div = 4.0f, delta = 2.0f;  // para[] for the 2003 set, delta_d (ADC/performance_eval.h:13-15)
     int device = 0;
     for (int i = 4; i + 1 < argc; i += 2) {
@@ -34,6 +36,9 @@ int main(int argc, char **argv) {
         else if (k == "--gt-div") gt_div = (float)std::atof(v);
         else if (k == "--delta") delta = (float)std::atof(v);
         else if (k == "--raw") raw_path = v;
+        else if (k == "--gt-pfm") gt_pfm = v;
+        else if (k == "--calib") calib_path = v;
+        else if (k == "--depth") depth_path = v;
         else if (k == "--device") device = std::atoi(v);
         else { std::fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
     }
@@ -84,6 +89,29 @@ int main(int argc, char **argv) {
         std::printf("\nEvalution:\n  RMS = %.3f\n  PEP = %.3f (bad %.1f)\n  Mde = %.3f\n", rms, pep, delta, mde);  // performance_eval.cpp:252
         std::printf("PEP_exact = %.9g\n", pep);
         adc_image_free(gt);
+    }
+    if (!gt_pfm.empty()) {
+        float *gt = nullptr;
+        int gw = 0, gh = 0;
+        if (adc_pfm_read(gt_pfm.c_str(), &gt, &gw, &gh) || gw != w || gh != h) {
+            std::fprintf(stderr, "cannot use ground truth %s\n", gt_pfm.c_str());
+            return -4;
+        }
+        float rms = 0, pep = 0, mde = 0;
+        adc_eval_pfm(disp.data(), gt, w, h, delta, secs, &rms, &pep, &mde);
+        std::printf("\nEvalution:\n  RMS = %.3f\n  PEP = %.3f (bad %.1f)\n  Mde = %.3f\n", rms, pep, delta, mde);  // performance_eval.cpp:213
+        adc_float_free(gt);
+    }
+    if (!depth_path.empty()) {
+        float focal = 0, baseline = 0, doffs = 0;
+        if (calib_path.empty() || adc_calib_read(calib_path.c_str(), &focal, &baseline, &doffs)) {
+            std::fprintf(stderr, "--depth needs a readable --calib file\n");
+            return -5;
+        }
+        float lo = 0, hi = 0;
+        adc_disparity_to_depth(disp.data(), w, h, focal, baseline, doffs, nullptr, img.data(), &lo, &hi);
+        std::printf("max_depth%g\nmin_depth%g\n", hi, lo);                // ADC/main.cpp:529-530
+        if (adc_png_write_gray(depth_path.c_str(), img.data(), w, h)) return -3;
     }
     adc_image_free(left);
     adc_image_free(right);

@@ -84,6 +84,39 @@ def test_eval_0103(pkg, orc, horc, name):
     assert abs(pep - bad) < 1e-6 and abs(rms - rms64) < 1e-3
 
 
+def test_pfm_round_trip_and_eval(pkg, horc, tmp_path):
+    rng = np.random.default_rng(6)
+    gt = (rng.random((37, 53), dtype=np.float32) * 200).astype(np.float32)
+    gt[rng.random((37, 53)) < 0.1] = np.inf                  # unknown ground truth
+    p = str(tmp_path / "disp0.pfm")
+    pkg.adcensus.pfm_write(p, gt)
+    assert np.array_equal(horc.pfm_read(p), gt)              # an independent reader agrees (bottom-up rows)
+    assert np.array_equal(pkg.adcensus.pfm_read(p), gt)
+    open(str(tmp_path / "c.pfm"), "wb").write(b"PF\n2 2\n-1.0\n" + bytes(48))
+    with pytest.raises(IOError):
+        pkg.adcensus.pfm_read(str(tmp_path / "c.pfm"))        # colour PFM: not a disparity map
+    est = (gt + rng.normal(0, 1.5, gt.shape)).astype(np.float32)
+    est[np.isinf(est)] = 17.0
+    got, want = pkg.adcensus.eval_pfm(est, gt, 2.0, 0.25), horc.eval_pfm(est, gt, 2.0, 0.25)
+    assert got[1] == want[1] and abs(got[0] - want[0]) <= 1e-6 * want[0] and got[2] == want[2]
+    est[3, 4] = np.inf                                       # one invalid estimate: RMS and Mde go to infinity
+    got = pkg.adcensus.eval_pfm(est, gt, 2.0, 0.25)
+    assert np.isinf(got[0]) and np.isinf(got[2]) and got[1] == horc.eval_pfm(est, gt, 2.0, 0.25)[1]
+
+
+def test_depth_and_calib(pkg, horc):
+    f, b, doffs = pkg.adcensus.calib_read(os.path.join(DATA, "artroom1", "calib.txt"))
+    assert (round(f, 2), round(b, 2), doffs) == (1733.74, 536.62, 0.0)   # the reference's table entry 0 (main.cpp:9-18)
+    z = np.load(os.path.join(GOLDEN, "teddy_disp.npz"))
+    d = z["disp_final"].copy()
+    d[0, :5] = [np.inf, 0.0, -3.0, 1.0, 60.0]
+    depth, u8, lo, hi = pkg.adcensus.disparity_to_depth(d, f, b, doffs)
+    o_depth, o_u8, o_lo, o_hi = horc.depth(d, f, b, doffs)
+    assert np.array_equal(depth, o_depth) and np.array_equal(u8, o_u8) and (lo, hi) == (o_lo, o_hi)
+    assert depth[0, 0] == 0 and depth[0, 1] == 0 and depth[0, 2] == np.float32(np.float32(f) * np.float32(b) / np.float32(3.0))
+    assert lo == 0.0                                          # a zero anywhere pulls the minimum to 0, as in the reference
+
+
 @pytest.mark.gpu
 def test_cli_end_to_end(pkg, orc, tmp_path):
     """adc_match: PNGs in -> disparity.png + evaluation block, against the library called directly."""
