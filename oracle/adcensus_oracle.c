@@ -56,6 +56,28 @@ static inline int imax_(int a, int b) { return a > b ? a : b; }
 static inline int imin_(int a, int b) { return a < b ? a : b; }
 static inline float fmin_(float a, float b) { return a < b ? a : b; }
 
+/* Literal-defect switches (sensitivity study only; 0 = canonical, the only mode the parity tests
+ * and the CPU baseline use). */
+static unsigned g_literal = 0;
+void orc_set_literal(unsigned flags) { g_literal = flags; }
+unsigned orc_get_literal(void) { return g_literal; }
+
+/* What `MAX(a, MAX(b, c))` evaluates to with `#define MAX(a,b) (a>b)?(a):(b)` (ADC/config.h:72):
+ * the text becomes (a>(b>c)?(b):(c))?(a):((b>c)?(b):(c)), i.e. the condition is
+ * ((a > (b>c)) ? b : c) != 0 and the result is a when it holds, else max(b,c). */
+int orc_literal_max3(int a, int b, int c) {
+    const int cond = (a > (b > c)) ? b : c;
+    return cond ? a : ((b > c) ? b : c);
+}
+
+/* What `MIN(MIN(l1,l2), MIN(l3,l4))` evaluates to with `#define MIN(a,b) (a<b)?(a):(b)`
+ * (ADC/config.h:71): ((l1<l2)?(l1):(l2)<(l3<l4)?(l3):(l4)) ? min(l1,l2) : min(l3,l4); the condition
+ * parses as (l1<l2) ? l1 : ((l2 < (float)(l3<l4)) ? l3 : l4), taken as a truth value. */
+float orc_literal_min4(float l1, float l2, float l3, float l4) {
+    const float cond = (l1 < l2) ? l1 : ((l2 < (float)(l3 < l4)) ? l3 : l4);
+    return (cond != 0.0f) ? ((l1 < l2) ? l1 : l2) : ((l3 < l4) ? l3 : l4);
+}
+
 /* ColorDist, ADC/cross_aggregator.h:73-75: max over channels of |difference|. */
 static inline int color_dist(const uint8_t *p, const uint8_t *q) {
     return imax_(iabs_((int)p[2] - (int)q[2]), imax_(iabs_((int)p[1] - (int)q[1]), iabs_((int)p[0] - (int)q[0])));
@@ -263,9 +285,17 @@ void orc_aggregate(float *cost, const uint8_t *arms, const uint16_t *cnt_h, cons
  *   (P1,P2) = (p1,p2) | (p1/4,p2/4) | (p1/10,p2/10) by how many of d1,d2 reach tso (:97-109)
  *   dst = (src + min(Lp[d], Lp[d-1]+P1, Lp[d+1]+P1, min(Lp)+P2)) / 2 (:112-121) with Lp[-1] = Lp[D]
  *      = Large_Float. */
-void orc_scanline_pass(const uint8_t *L, const uint8_t *R, const float *src, float *dst,
-                       int W, int H, int dmin, int dmax, float p1, float p2, int tso,
-                       int vertical, int forward) {
+static inline __attribute__((always_inline)) int path_dist(const uint8_t *p, const uint8_t *q, unsigned lit) {
+    if (lit & ORC_LIT_MAX_MACRO)   /* argument order of ADC/scanline_optimizer.cu:73-74: channels 0,1,2 */
+        return orc_literal_max3(iabs_((int)p[0] - (int)q[0]), iabs_((int)p[1] - (int)q[1]),
+                                iabs_((int)p[2] - (int)q[2]));
+    return color_dist(p, q);
+}
+
+static inline __attribute__((always_inline)) void
+scanline_pass_body(const uint8_t *L, const uint8_t *R, const float *src, float *dst,
+                   int W, int H, int dmin, int dmax, float p1, float p2, int tso,
+                   int vertical, int forward, const unsigned lit) {
     const int D = dmax - dmin;
     const int dir = forward ? 1 : -1;
     const int nlines = vertical ? W : H;
@@ -284,18 +314,31 @@ void orc_scanline_pass(const uint8_t *L, const uint8_t *R, const float *src, flo
             last[0] = ORC_LARGE;
             last[D + 1] = ORC_LARGE;
             float minlast = ORC_LARGE;
+            if (lit & ORC_LIT_LOW_SENTINEL) {
+                /* memset(p, Large_Float, D + 2) writes the byte 0x9F (99999 & 0xFF) over the first D+2
+                 * BYTES (ADC/scanline_optimizer.cu:45,194); the memcpy that follows rewrites elements
+                 * 1..D, so only element 0 keeps 0x9F9F9F9F (about -6.8e-20) for the whole path, and the
+                 * initial minimum (:61-64) sees it. Element D+1 lies partly outside the allocation and
+                 * is indeterminate in the shipped code; it stays Large_Float here. */
+                const uint32_t bits = 0x9F9F9F9Fu;
+                memcpy(&last[0], &bits, 4);
+                minlast = fmin_(minlast, last[0]);
+            }
             for (int k = 0; k < D; k++) {
                 o[k] = s[k];
                 last[k + 1] = o[k];
                 minlast = fmin_(minlast, o[k]);
             }
+            if ((lit & ORC_LIT_HPASS_RETURN) && !vertical)
+                continue; /* `return;` as the first statement of the disparity loop, ADC/scanline_optimizer.cu:78:
+                             the path head is copied and the thread exits; dst keeps what it held */
             const uint8_t *plast = L + ((size_t)y * W + x) * 3;
             for (int step = 1; step < len; step++) {
                 if (vertical) y += dir; else x += dir;
                 s = src + ((size_t)y * W + x) * D;
                 o = dst + ((size_t)y * W + x) * D;
                 const uint8_t *pc = L + ((size_t)y * W + x) * 3;
-                const int d1 = color_dist(pc, plast);
+                const int d1 = path_dist(pc, plast, lit);
                 int d2 = d1;
                 float mn = ORC_LARGE;
                 for (int k = 0; k < D; k++) {
@@ -304,7 +347,7 @@ void orc_scanline_pass(const uint8_t *L, const uint8_t *R, const float *src, flo
                         const uint8_t *rc = R + ((size_t)y * W + xr) * 3;
                         const uint8_t *rp = vertical ? R + ((size_t)(y - dir) * W + xr) * 3
                                                      : R + ((size_t)y * W + (xr - dir)) * 3;
-                        d2 = color_dist(rc, rp);
+                        d2 = path_dist(rc, rp, lit);
                     }
                     const int sel = (d1 >= tso) + (d2 >= tso);
                     const float P1 = P1t[sel], P2 = P2t[sel];
@@ -312,7 +355,8 @@ void orc_scanline_pass(const uint8_t *L, const uint8_t *R, const float *src, flo
                     const float l2 = last[k] + P1;
                     const float l3 = last[k + 2] + P1;
                     const float l4 = minlast + P2;
-                    float cs = s[k] + fmin_(fmin_(l1, l2), fmin_(l3, l4));
+                    float cs = s[k] + ((lit & ORC_LIT_MIN_MACRO) ? orc_literal_min4(l1, l2, l3, l4)
+                                                                 : fmin_(fmin_(l1, l2), fmin_(l3, l4)));
                     cs /= 2;
                     o[k] = cs;
                     mn = fmin_(mn, cs);
@@ -324,6 +368,15 @@ void orc_scanline_pass(const uint8_t *L, const uint8_t *R, const float *src, flo
         }
         free(last);
     }
+}
+
+void orc_scanline_pass(const uint8_t *L, const uint8_t *R, const float *src, float *dst,
+                       int W, int H, int dmin, int dmax, float p1, float p2, int tso,
+                       int vertical, int forward) {
+    if (g_literal == 0)   /* the constant lets the compiler drop every literal branch from the canonical loop */
+        scanline_pass_body(L, R, src, dst, W, H, dmin, dmax, p1, p2, tso, vertical, forward, 0u);
+    else
+        scanline_pass_body(L, R, src, dst, W, H, dmin, dmax, p1, p2, tso, vertical, forward, g_literal);
 }
 
 /* ScanlineOptimizer::Optimize, ADC/scanline_optimizer.cu:380-447: L->R aggr->init, R->L init->aggr,
@@ -505,11 +558,14 @@ void orc_interpolate(const uint8_t *L, const float *disp_in, float *disp_out,
     double sina[16], cosa[16];
     interp_dirs(sina, cosa);
     const int maxlen = iabs_(dmax) * 1;
+    const int row_return = (g_literal & ORC_LIT_INTERP_RETURN) != 0;
 #pragma omp parallel for schedule(dynamic, 4)
     for (int y = 0; y < H; y++) {
+        int dead = 0; /* literal mode: the row's thread has returned (ADC/multistep_refiner.cu:586-588) */
         for (int x = 0; x < W; x++) {
             const size_t i = (size_t)y * W + x;
             disp_out[i] = disp_in[i];
+            if (dead) continue;
             if (!(occ[i] || mis[i])) continue;
             float cd[16];
             size_t cidx[16];
@@ -528,7 +584,7 @@ void orc_interpolate(const uint8_t *L, const float *disp_in, float *disp_out,
                     }
                 }
             }
-            if (!num) continue;
+            if (!num) { dead = row_return; continue; }
             if (mis[i]) {
                 int mind = 9999;
                 float d = 0.0f;

@@ -113,6 +113,20 @@ double orc_bad_fraction(const float *disp, const uint8_t *gt, int W, int H, floa
 
 int orc_num_threads(void);
 
+/* Literal-defect switches: reproduce, one by one, deterministic defects of the shipped CUDA code that
+ * the canonical semantics above repair. They exist to measure how far canonical output is from what
+ * the shipped binary most likely produced; no parity test or baseline uses a non-zero value. The
+ * setting is process-wide and applies to the orc_* calls that follow. */
+#define ORC_LIT_HPASS_RETURN   1u  /* stray `return;` in the horizontal scanline kernel, ADC/scanline_optimizer.cu:78 */
+#define ORC_LIT_MIN_MACRO      2u  /* nested unparenthesised MIN, ADC/config.h:71 at ADC/scanline_optimizer.cu:118,267 */
+#define ORC_LIT_MAX_MACRO      4u  /* nested unparenthesised MAX, ADC/config.h:72 at ADC/scanline_optimizer.cu:73-74,90-91,220-221,239-240 */
+#define ORC_LIT_INTERP_RETURN  8u  /* `return;` for `continue;`, ADC/multistep_refiner.cu:586-588 */
+#define ORC_LIT_LOW_SENTINEL  16u  /* memset(p, Large_Float, D+2): Lp[-1] = 0x9F9F9F9F, ADC/scanline_optimizer.cu:42-45,190-194 */
+void orc_set_literal(unsigned flags);
+unsigned orc_get_literal(void);
+int orc_literal_max3(int a, int b, int c);
+float orc_literal_min4(float l1, float l2, float l3, float l4);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,7 +72,40 @@ def lib():
         _lib.orc_match.restype = C.c_int
         _lib.orc_bad_fraction.restype = C.c_double
         _lib.orc_num_threads.restype = C.c_int
+        _lib.orc_get_literal.restype = C.c_uint
+        _lib.orc_literal_max3.restype = C.c_int
+        _lib.orc_literal_min4.restype = C.c_float
+        _lib.orc_literal_min4.argtypes = [C.c_float] * 4
     return _lib
+
+
+LIT_HPASS_RETURN, LIT_MIN_MACRO, LIT_MAX_MACRO, LIT_INTERP_RETURN, LIT_LOW_SENTINEL = 1, 2, 4, 8, 16
+LIT_ALL = 31
+
+
+class literal:
+    """Context manager: run the enclosed oracle calls with the given literal-defect switches
+    (sensitivity study only; parity tests and baselines always run with 0)."""
+
+    def __init__(self, flags):
+        self.flags = int(flags)
+
+    def __enter__(self):
+        self.prev = lib().orc_get_literal()
+        lib().orc_set_literal(C.c_uint(self.flags))
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_literal(C.c_uint(self.prev))
+        return False
+
+
+def literal_max3(a, b, c):
+    return lib().orc_literal_max3(C.c_int(a), C.c_int(b), C.c_int(c))
+
+
+def literal_min4(l1, l2, l3, l4):
+    return lib().orc_literal_min4(l1, l2, l3, l4)
 
 
 def default_option(**kw):

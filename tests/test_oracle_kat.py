@@ -430,3 +430,95 @@ def test_middlebury_bad2(orc, name, expected):
     bad, rms = orc.bad_fraction(disp, gt, 4.0, 2.0)
     assert bad < 0.12                                  # an AD-Census implementation lands well under this on 2003 scenes
     assert abs(bad - expected) < 1e-12                 # value recorded when the oracle was written
+
+
+# ---- literal-defect switches (sensitivity study only; canonical = 0 is what every parity test uses) ----
+
+def test_literal_macro_expansions(orc):
+    # MAX(a, MAX(b, c)) with the unparenthesised macro (config.h:72): condition ((a > (b>c)) ? b : c) != 0
+    assert orc.literal_max3(5, 10, 3) == 5          # true maximum would be 10
+    assert orc.literal_max3(0, 7, 9) == 0           # (0 > (7>9)) false -> cond = c = 9, non-zero -> a
+    for a in range(0, 6):
+        for b in range(0, 6):
+            for c in range(0, 6):
+                cond = (b if a > int(b > c) else c)
+                assert orc.literal_max3(a, b, c) == (a if cond else max(b, c))
+    # MIN(MIN(l1,l2), MIN(l3,l4)) (config.h:71): min(l1,l2) unless the selected condition value is 0
+    assert orc.literal_min4(2.0, 3.0, 0.5, 0.25) == 2.0      # l3, l4 ignored
+    assert orc.literal_min4(3.0, 2.5, 0.5, 0.25) == 2.5
+    assert orc.literal_min4(0.0, 3.0, 7.0, 5.0) == 5.0       # l1<l2 and l1 == 0 -> min(l3,l4)
+    assert orc.literal_min4(3.0, 2.0, 0.0, 5.0) == 2.0       # l2 !< (l3<l4)=1 -> cond=l4=5 -> min(l1,l2)
+    assert orc.literal_min4(3.0, 0.5, 0.0, 5.0) == 0.0       # l2 < 1 -> cond=l3=0 -> min(l3,l4)
+
+
+def test_literal_zero_is_canonical_and_restores(orc):
+    rng = np.random.default_rng(5)
+    L = rng.integers(0, 256, (12, 20, 3), dtype=np.uint8)
+    R = rng.integers(0, 256, (12, 20, 3), dtype=np.uint8)
+    opt = orc.default_option(max_disparity=8)
+    base, _ = orc.match(L, R, opt)
+    with orc.literal(0):
+        again, _ = orc.match(L, R, opt)
+    assert np.array_equal(base.view(np.uint32), again.view(np.uint32))
+    with orc.literal(orc.LIT_ALL):
+        assert orc.lib().orc_get_literal() == orc.LIT_ALL
+    assert orc.lib().orc_get_literal() == 0
+    after, _ = orc.match(L, R, opt)
+    assert np.array_equal(base.view(np.uint32), after.view(np.uint32))
+
+
+def test_literal_horizontal_pass_only_copies_the_path_head(orc):
+    rng = np.random.default_rng(6)
+    H, W, D = 5, 9, 4
+    L = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    R = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    src = rng.random((H, W, D), dtype=np.float32)
+    held = np.full((H, W, D), -7.0, np.float32)
+
+    def run(vertical, forward):
+        import ctypes as C
+        dst = held.copy()
+        orc.lib().orc_scanline_pass(L.ctypes.data_as(C.c_void_p), R.ctypes.data_as(C.c_void_p),
+                                    src.ctypes.data_as(C.c_void_p), dst.ctypes.data_as(C.c_void_p),
+                                    C.c_int(W), C.c_int(H), C.c_int(0), C.c_int(D), C.c_float(1.0), C.c_float(3.0),
+                                    C.c_int(15), C.c_int(int(vertical)), C.c_int(int(forward)))
+        return dst
+
+    with orc.literal(orc.LIT_HPASS_RETURN):
+        fwd, bwd, vert = run(False, True), run(False, False), run(True, True)
+    assert np.array_equal(fwd[:, 0], src[:, 0]) and np.all(fwd[:, 1:] == -7.0)
+    assert np.array_equal(bwd[:, -1], src[:, -1]) and np.all(bwd[:, :-1] == -7.0)
+    assert np.array_equal(vert, orc.scanline_pass(L, R, src, 0, D, vertical=True, forward=True))  # vertical untouched
+
+
+def test_literal_low_sentinel_changes_only_what_reads_it(orc):
+    # one row, D=3, left->right: at k=0 the term Lp[-1]+P1 is P1 - 6.8e-20 = P1 instead of 99999+P1
+    L = np.zeros((1, 3, 3), np.uint8)
+    R = np.zeros((1, 3, 3), np.uint8)
+    src = np.array([[[5.0, 6.0, 7.0], [1.0, 1.0, 1.0], [1.0, 1.0, 1.0]]], np.float32)
+    canon = orc.scanline_pass(L, R, src, 0, 3)
+    with orc.literal(orc.LIT_LOW_SENTINEL):
+        lit = orc.scanline_pass(L, R, src, 0, 3)
+    assert np.array_equal(canon[0, 0], lit[0, 0])
+    # canonical x=1,k=0: min(5, 99999+1, 6+1, 5+3) = 5 -> (1+5)/2 = 3
+    assert canon[0, 1, 0] == np.float32(3.0)
+    # literal: initial min includes -6.8e-20 -> l4 = 3.0 (absorbed); l2 = 1.0 -> (1+1)/2 = 1
+    assert lit[0, 1, 0] == np.float32(1.0)
+    # k=2 does not read Lp[-1] but does read the polluted initial minimum: min(7, 6+1, 99999+1, -6.8e-20+3) = 3
+    assert lit[0, 1, 2] == np.float32(2.0) and canon[0, 1, 2] == np.float32(4.0)
+
+
+def test_literal_interpolation_return_abandons_the_row(orc):
+    H, W = 4, 8
+    inf = np.float32(np.inf)
+    disp = np.full((H, W), inf, np.float32)
+    disp[2, 7] = 3.0
+    L = np.zeros((H, W, 3), np.uint8)
+    mis = np.isinf(disp).astype(np.uint8)
+    occ = np.zeros((H, W), np.uint8)
+    canon = orc.interpolate(L, disp, occ, mis, 3)          # search length 3 -> m = 1, 2
+    assert canon[2, 5] == 3.0 and canon[2, 6] == 3.0 and np.isinf(canon[2, :5]).all()
+    with orc.literal(orc.LIT_INTERP_RETURN):
+        lit = orc.interpolate(L, disp, occ, mis, 3)
+    assert np.isinf(lit[2, :7]).all() and lit[2, 7] == 3.0  # (2,0) collected nothing -> the row's thread returned
+    assert not np.isinf(canon[0, 6:]).any() and np.isinf(lit[0]).all()   # row 0 died at x=0 as well
