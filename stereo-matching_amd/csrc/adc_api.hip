@@ -55,6 +55,9 @@ struct adc_handle {
     uint32_t *list_mis = nullptr, *list_occ = nullptr, *counters = nullptr;
     uint32_t *list2_mis = nullptr, *list2_occ = nullptr;   // the entries still unfilled after voting
     float *newval = nullptr;
+    uint32_t *tile_stamp = nullptr; // per 8x8 tile: stamp of the last voting pass that filled a pixel in it
+    uint32_t vote_stamp = 16;       // first stamp of the next frame (stamps only grow, the array is never cleared)
+    uint32_t *list3_mis = nullptr, *list3_occ = nullptr;   // with list2_*: ping-pong lists of the entries still open between voting passes
     short *binmap = nullptr;       // histogram bin of every pixel of the current disparity map (voting), -1 = none
     // debug snapshots
     float *snap_wta_l = nullptr, *snap_outlier = nullptr, *snap_voting = nullptr, *snap_interp = nullptr;
@@ -175,10 +178,12 @@ int do_initialize(adc_handle *h, int32_t W, int32_t H, const adc_option *opt) {
     A(h->lut_ad, 768); A(h->lut_cen, 68);
     A(h->disp_a, npx); A(h->disp_b, npx); A(h->disp_r, npx); A(h->disp_final, npx);
     A(h->occ, npx); A(h->mis, npx); A(h->edge, npx);
-    A(h->list_mis, npx); A(h->list_occ, npx); A(h->counters, 4);
+    A(h->list_mis, npx); A(h->list_occ, npx); A(h->counters, ADC_NUM_COUNTERS);
     A(h->list2_mis, npx); A(h->list2_occ, npx);
+    A(h->list3_mis, npx); A(h->list3_occ, npx);
     A(h->newval, 2 * npx);
     A(h->binmap, npx);
+    A(h->tile_stamp, (size_t)vote_tiles_w(W) * vote_tiles_h(H));
     A(h->tap_u64, npx);
 #undef A
     if ((rc = host_alloc(h, &h->h_bgr_l, npx * 3))) return rc;
@@ -187,6 +192,8 @@ int do_initialize(adc_handle *h, int32_t W, int32_t H, const adc_option *opt) {
     // padding columns of the volumes are never produced by the cost kernel; give them a defined value once
     HIPCHK(h, hipMemsetAsync(h->vol_a, 0, nvol * sizeof(float), h->stream));
     HIPCHK(h, hipMemsetAsync(h->vol_b, 0, nvol * sizeof(float), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->tile_stamp, 0, (size_t)vote_tiles_w(W) * vote_tiles_h(H) * sizeof(uint32_t), h->stream));
+    h->vote_stamp = 16;
 
     // exp tables of the initial cost (ADC/cost_computor.cu:186,200-203): entry = expf of the float
     // argument, taken as the correctly rounded (float)exp((double)arg).
@@ -332,11 +339,25 @@ int enqueue_match(adc_handle *h, const uint8_t *d_l, const uint8_t *d_r, float *
     snap(h->snap_occ, h->occ, npx);
     snap(h->snap_mis, h->mis, npx);
     if (o.do_filling) {  // drives both voting and interpolation (ADC/ADCensusStereo.cu:195-196)
+        if (h->vote_stamp > 0xffffff00u) {   // stamps would wrap: start over
+            hipMemsetAsync(h->tile_stamp, 0, (size_t)vote_tiles_w(g.W) * vote_tiles_h(g.H) * sizeof(uint32_t), s);
+            h->vote_stamp = 16;
+        }
+        const uint32_t stamp0 = h->vote_stamp;
+        h->vote_stamp += 16;
+        // Each pass hands its still-open entries to the list's next pass: full list -> list2 -> list3 -> list2 -> list3.
+        const uint32_t *in_mis = h->list_mis, *in_occ = h->list_occ;
+        uint32_t *n_mis = h->counters + 0, *n_occ = h->counters + 1;
         for (int it = 0; it < 5; it++) {  // IterativeNums (ADC/config.h:46): mismatch pass, then occlusion pass
-            launch_region_voting_pass(cur, h->binmap, h->mis, h->list_mis, h->counters + 0, h->newval, pl.arms, g, o.irv_ts,
-                                      o.irv_th, s);
-            launch_region_voting_pass(cur, h->binmap, h->occ, h->list_occ, h->counters + 1, h->newval, pl.arms, g, o.irv_ts,
-                                      o.irv_th, s);
+            const bool last = it == 4;
+            uint32_t *out_mis = last ? nullptr : (it % 2 == 0 ? h->list2_mis : h->list3_mis);
+            uint32_t *out_occ = last ? nullptr : (it % 2 == 0 ? h->list2_occ : h->list3_occ);
+            launch_region_voting_pass(cur, h->binmap, h->mis, in_mis, n_mis, out_mis, h->counters + 4 + 2 * it, h->newval,
+                                      pl.arms, h->tile_stamp, stamp0, 2 * it, cap, g, o.irv_ts, o.irv_th, s);
+            launch_region_voting_pass(cur, h->binmap, h->occ, in_occ, n_occ, out_occ, h->counters + 5 + 2 * it, h->newval,
+                                      pl.arms, h->tile_stamp, stamp0, 2 * it + 1, cap, g, o.irv_ts, o.irv_th, s);
+            in_mis = out_mis; in_occ = out_occ;
+            n_mis = h->counters + 4 + 2 * it; n_occ = h->counters + 5 + 2 * it;
         }
     }
     snap(h->snap_voting, cur, npx * sizeof(float));

@@ -85,9 +85,17 @@ void launch_outlier(const float *dl, const float *dr, float *out, uint8_t *occ, 
                     uint32_t *list_mis, uint32_t *list_occ, uint32_t *counters,
                     const Geom &g, float thres, hipStream_t s);
 void launch_clear_masks(uint8_t *occ, uint8_t *mis, uint32_t *counters, size_t n, hipStream_t s);
+// counters: [0] mismatch, [1] occlusion entries found by the outlier check; [2], [3] entries handed to the
+// interpolation; [4 + p] entries still open after voting pass p (0..9)
+#define ADC_NUM_COUNTERS 16
+int vote_tiles_w(int W);
+int vote_tiles_h(int H);
+// pass: 0..9 within the frame (even = mismatch list, odd = occlusion list); stamp0: the frame's first stamp,
+// larger than every stamp of earlier frames; cap: the arm length cap (bounds a region's horizontal extent)
+// out_list / out_count (may be null): receive the entries still open after this pass, for the list's next pass
 void launch_region_voting_pass(float *disp, short *binmap, uint8_t *mask, const uint32_t *list, const uint32_t *count,
-                               float *newval, const uint32_t *arms, const Geom &g, int tau_s, float tau_h,
-                               hipStream_t s);
+                               uint32_t *out_list, uint32_t *out_count, float *newval, const uint32_t *arms, uint32_t *tile_stamp, uint32_t stamp0, int pass,
+                               int cap, const Geom &g, int tau_s, float tau_h, hipStream_t s);
 void launch_interpolate(float *disp, const uint8_t *occ, const uint8_t *mis,
                         const uint32_t *list_mis, const uint32_t *list_occ, uint32_t *list2_mis, uint32_t *list2_occ,
                         uint32_t *counters, float *newval, const uint32_t *pix_l, const double *ray_dy,

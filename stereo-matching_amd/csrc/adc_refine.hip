@@ -96,7 +96,7 @@ k_outlier(const float *__restrict__ dl, const float *__restrict__ dr, float *__r
 void launch_outlier(const float *dl, const float *dr, float *out, uint8_t *occ, uint8_t *mis, short *binmap,
                     uint32_t *list_mis, uint32_t *list_occ, uint32_t *counters,
                     const Geom &g, float thres, hipStream_t s) {
-    hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), s);
+    hipMemsetAsync(counters, 0, ADC_NUM_COUNTERS * sizeof(uint32_t), s);
     dim3 grid((g.W + 63) / 64, (g.H + OUT_WAVES - 1) / OUT_WAVES);
     k_outlier<<<grid, dim3(64 * OUT_WAVES), 0, s>>>(dl, dr, out, occ, mis, binmap, list_mis, list_occ, counters,
                                                     g.W, g.H, g.dmin, g.D, thres);
@@ -105,7 +105,7 @@ void launch_outlier(const float *dl, const float *dr, float *out, uint8_t *occ, 
 void launch_clear_masks(uint8_t *occ, uint8_t *mis, uint32_t *counters, size_t n, hipStream_t s) {
     hipMemsetAsync(occ, 0, n, s);
     hipMemsetAsync(mis, 0, n, s);
-    hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), s);
+    hipMemsetAsync(counters, 0, ADC_NUM_COUNTERS * sizeof(uint32_t), s);
 }
 
 // ---- iterative region voting (RegionVotingCuda + DeleteFilledPixel, ADC/multistep_refiner.cu:376-449)
@@ -113,21 +113,52 @@ void launch_clear_masks(uint8_t *occ, uint8_t *mis, uint32_t *counters, size_t n
 // support region is built in LDS. The arms of up to 64 region rows are fetched with one load (lane <->
 // row); each row's horizontal span is then read with lanes along the row, VOTE_ROWS rows per batch so
 // that their loads are in flight together instead of one dependent round trip per row.
+//
+// A pixel that failed the vote fails it again for as long as no disparity inside its support region has
+// changed, so from a list's second pass on the histogram is rebuilt only for pixels that had a fill
+// land near them since they were last looked at. Fills are tracked per 8x8 tile: k_apply stamps the
+// tile with the pass number, and a pixel is re-voted when any tile touching the bounding box of its
+// region (its own vertical arms, the arm cap horizontally) carries a stamp from the two passes since
+// its previous turn. Stamps grow monotonically over frames (stamp0 = this frame's pass 0), so the tile
+// array is never cleared.
 #define VOTE_ROWS 8
+#ifndef VOTE_TILE_SHIFT
+#define VOTE_TILE_SHIFT 3
+#endif
+#ifndef VOTE_SKIP_FROM
+#define VOTE_SKIP_FROM 2
+#endif
 __global__ void __launch_bounds__(64)
 k_vote(const float *__restrict__ disp, const short *__restrict__ binmap, const uint8_t *__restrict__ mask,
        const uint32_t *__restrict__ list, const uint32_t *__restrict__ count, float *__restrict__ newval,
-       const uint32_t *__restrict__ arms, int W, int dmin, int D, int tau_s, float tau_h) {
+       const uint32_t *__restrict__ arms, const uint32_t *__restrict__ tile_stamp, int W, int dmin, int D,
+       int tau_s, float tau_h, int cap, int tiles_w, uint32_t stamp0, int pass) {
     extern __shared__ int hist[];
     const int lane = threadIdx.x;
     const uint32_t n = *count;
     for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
         const uint32_t p = list[e];
         float result = ADC_INF;
-        if (mask[p] && disp[p] == ADC_INF) {   // uniform across the wave
+        bool todo = mask[p] && disp[p] == ADC_INF;   // uniform across the wave
+        uint32_t a = 0;
+        if (todo) {
+            a = arms[p];
+            if (pass >= VOTE_SKIP_FROM) {
+                const int y = (int)(p / (uint32_t)W), x = (int)(p - (uint32_t)y * (uint32_t)W);
+                const int tx0 = max(x - cap, 0) >> VOTE_TILE_SHIFT, tx1 = min(x + cap, W - 1) >> VOTE_TILE_SHIFT;
+                const int ty0 = (y - (int)((a >> 16) & 0xff)) >> VOTE_TILE_SHIFT, ty1 = (y + (int)(a >> 24)) >> VOTE_TILE_SHIFT;
+                const int ntx = tx1 - tx0 + 1, nt = ntx * (ty1 - ty0 + 1);
+                bool fresh = false;
+                for (int t = lane; t < nt; t += 64) {
+                    const int ty = ty0 + t / ntx, tx = tx0 + t % ntx;
+                    fresh |= tile_stamp[ty * tiles_w + tx] >= stamp0 + (uint32_t)(pass - 2);
+                }
+                todo = __ballot(fresh) != 0ull;
+            }
+        }
+        if (todo) {
             for (int k = lane; k < D; k += 64) hist[k] = 0;
             __syncthreads();
-            const uint32_t a = arms[p];
             const int top = (a >> 16) & 0xff, bot = a >> 24;
             const int nrows = top + bot + 1;
             for (int r0 = 0; r0 < nrows; r0 += 64) {
@@ -190,28 +221,65 @@ k_vote(const float *__restrict__ disp, const short *__restrict__ binmap, const u
     }
 }
 
+// Writes the pass's fills, and hands the entries that are still open to the list's next pass (out_list /
+// out_count, skipped when null): a filled pixel never comes back, so later passes walk ever shorter lists
+// instead of the whole outlier list. Appends are aggregated per workgroup (ballot -> per-wave counts ->
+// one reservation) as in k_outlier. The order of a list does not matter: every entry is voted on its own.
 __global__ void __launch_bounds__(256)
 k_apply(float *__restrict__ disp, short *__restrict__ binmap, uint8_t *__restrict__ mask,
         const uint32_t *__restrict__ list, const uint32_t *__restrict__ count, const float *__restrict__ newval,
-        int dmin, int D) {
+        uint32_t *__restrict__ out_list, uint32_t *__restrict__ out_count,
+        uint32_t *__restrict__ tile_stamp, int W, int dmin, int D, int tiles_w, uint32_t stamp) {
+    __shared__ uint32_t s_off[4];
     const uint32_t n = *count;
-    for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
-        const float v = newval[e];
-        if (v != ADC_INF) {
-            const uint32_t p = list[e];
-            disp[p] = v;
-            binmap[p] = vote_bin(v, dmin, D);
-            mask[p] = 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t e0 = blockIdx.x * 256u; e0 < n; e0 += gridDim.x * 256u) {   // uniform per workgroup
+        const uint32_t e = e0 + threadIdx.x;
+        bool keep = false;
+        uint32_t p = 0;
+        if (e < n) {
+            const float v = newval[e];
+            p = list[e];
+            if (v != ADC_INF) {
+                disp[p] = v;
+                binmap[p] = vote_bin(v, dmin, D);
+                mask[p] = 0;
+                const uint32_t y = p / (uint32_t)W, x = p - y * (uint32_t)W;
+                tile_stamp[(y >> VOTE_TILE_SHIFT) * (uint32_t)tiles_w + (x >> VOTE_TILE_SHIFT)] = stamp;   // every writer stores the same value
+            } else {
+                keep = mask[p] && disp[p] == ADC_INF;   // only this entry's own fill could change either
+            }
+        }
+        if (out_list) {
+            const unsigned long long m = __ballot(keep);
+            if (lane == 0) s_off[wave] = (uint32_t)__popcll(m);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const uint32_t c0 = s_off[0], c1 = s_off[1], c2 = s_off[2], c3 = s_off[3];
+                const uint32_t tot = c0 + c1 + c2 + c3;
+                const uint32_t base = tot ? atomicAdd(out_count, tot) : 0u;
+                s_off[0] = base; s_off[1] = base + c0; s_off[2] = base + c0 + c1; s_off[3] = base + c0 + c1 + c2;
+            }
+            __syncthreads();
+            if (keep) out_list[s_off[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = p;
+            __syncthreads();
         }
     }
 }
 
+int vote_tiles_w(int W) { return (W + (1 << VOTE_TILE_SHIFT) - 1) >> VOTE_TILE_SHIFT; }
+int vote_tiles_h(int H) { return (H + (1 << VOTE_TILE_SHIFT) - 1) >> VOTE_TILE_SHIFT; }
+
 void launch_region_voting_pass(float *disp, short *binmap, uint8_t *mask, const uint32_t *list, const uint32_t *count,
-                               float *newval, const uint32_t *arms, const Geom &g, int tau_s, float tau_h,
-                               hipStream_t s) {
+                               uint32_t *out_list, uint32_t *out_count,
+                               float *newval, const uint32_t *arms, uint32_t *tile_stamp, uint32_t stamp0, int pass,
+                               int cap, const Geom &g, int tau_s, float tau_h, hipStream_t s) {
+    const int tw = vote_tiles_w(g.W);
     k_vote<<<dim3(8192), dim3(64), (size_t)g.D * sizeof(int), s>>>(disp, binmap, mask, list, count, newval, arms,
-                                                                  g.W, g.dmin, g.D, tau_s, tau_h);
-    k_apply<<<dim3(512), dim3(256), 0, s>>>(disp, binmap, mask, list, count, newval, g.dmin, g.D);
+                                                                  tile_stamp, g.W, g.dmin, g.D, tau_s, tau_h, cap, tw,
+                                                                  stamp0, pass);
+    k_apply<<<dim3(512), dim3(256), 0, s>>>(disp, binmap, mask, list, count, newval, out_list, out_count, tile_stamp,
+                                            g.W, g.dmin, g.D, tw, stamp0 + (uint32_t)pass);
 }
 
 // ---- list compaction ---------------------------------------------------------------------------------

@@ -584,13 +584,195 @@ k_scanline_split(const float *__restrict__ src, float *__restrict__ dst, const u
     }
 }
 
+// The same pass with the per-pixel instruction count cut down (a wave issues at most one instruction
+// per 4-cycle turn, and with ~2 waves per SIMD nothing else fills the turns it wastes):
+//   * the path pointers live in scalar registers and advance by scalar adds; fills, the record fetch and
+//     the store address memory as scalar base + 32-bit lane offset,
+//   * the LDS-DMA pieces of one pixel share one M0 value (the instruction offset moves both addresses),
+//   * the loop is peeled (no end-of-path tests in the main part) and runs two pixels per trip, so the
+//     exchange parity is static and the "next pixel" registers swap roles instead of being copied,
+//   * every lane writes {wave minimum, its own boundary cost} to its own exchange slot; the other wave
+//     reads the slot of the lane next to the seam -- no execution-mask juggling around the LDS write.
+template <int NVW, int VERT>
+__global__ void __launch_bounds__(128)
+k_scanline_split2(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ rec,
+                  int W, int H, int Dp, int forward, ScanParams sp) {
+    typedef ScanCfgSplit<NVW> C;
+    constexpr int NV = NVW;
+    constexpr int RS = C::RS;
+    static_assert((RS & (RS - 1)) == 0, "ring size must be a power of two");
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __align__(16) uint8_t lds_raw[];
+    const int lane = threadIdx.x & 63;
+    const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0: low disparities, 1: high
+    const int line = blockIdx.x;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)lds_raw;
+    const uint32_t ring_off = lds0 + (uint32_t)half * RS * C::SLOT_B;
+    // exchange area: [parity][half][lane] x {wave minimum, boundary cost}
+    const uint32_t xch = lds0 + 2u * RS * C::SLOT_B;
+    const uint32_t xw = xch + (uint32_t)half * 512u + (uint32_t)lane * 8u;
+    const uint32_t xr = xch + (uint32_t)(1 - half) * 512u + (half ? 63u : 0u) * 8u;   // the other wave's lane at the seam
+    const int LEN = VERT ? H : W;
+    const int dir = forward ? 1 : -1;
+    const int kbase = half * 64 * NV;             // first disparity of this wave
+    const int k0 = kbase + lane * NV;
+    const int recw = 2 * C::NVF + 1;
+    const int x0 = VERT ? line : (forward ? 0 : W - 1);
+    const int y0 = VERT ? (forward ? 0 : H - 1) : line;
+    const ptrdiff_t pstep = VERT ? (ptrdiff_t)dir * W : (ptrdiff_t)dir;
+    const ptrdiff_t pix0 = (ptrdiff_t)y0 * W + x0;
+    const ptrdiff_t rshift = (VERT && !forward) ? (ptrdiff_t)W : 0;
+
+    // uniform byte addresses of path pixel 0 and the byte steps along the path
+    const char *const src_b = reinterpret_cast<const char *>(src + (size_t)pix0 * Dp + kbase);
+    char *const dst_b = reinterpret_cast<char *>(dst + (size_t)pix0 * Dp + kbase);
+    const char *const rec_b = reinterpret_cast<const char *>(rec + (size_t)(pix0 + rshift) * recw);
+    const ptrdiff_t vstep = pstep * (ptrdiff_t)Dp * 4;
+    const ptrdiff_t rstep = pstep * (ptrdiff_t)recw * 4;
+    const uint32_t vo_fill = (uint32_t)lane * (NV >= 4 ? 16u : 4u);
+    const uint32_t vo_rec = (uint32_t)lane * 4u;
+    const uint32_t vo_out = (uint32_t)lane * (uint32_t)(NV * 4);
+    const bool flag_lane = lane < recw;
+
+    auto issue_fill = [&](const char *sp_, const char *rp_, uint32_t slot) {
+        lds_void *l = (lds_void *)(uintptr_t)(ring_off + slot);
+        const char *g = sp_ + vo_fill;
+        static_assert(C::NDMA <= 2, "one or two LDS-DMA pieces per pixel and wave");
+        if constexpr (NV >= 4) {
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(g), l, 16, 0, 0);
+            if constexpr (C::NDMA == 2) __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(g), l, 16, 1024, 0);
+        } else {
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(g), l, 4, 0, 0);
+            if constexpr (C::NDMA == 2) __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(g), l, 4, 256, 0);
+        }
+        if (flag_lane)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(rp_ + vo_rec),
+                                             (lds_void *)(uintptr_t)(ring_off + slot + C::DATA_B), 4, 0, 0);
+    };
+    const uint32_t rd_data = ring_off + (uint32_t)(lane * NV) * 4u;
+    const uint32_t rd_bits = ring_off + C::DATA_B + (uint32_t)(k0 >> 3);
+    const uint32_t rd_f1 = ring_off + C::DATA_B + 8u * C::NVF;
+    auto read_slot = [&](uint32_t slot, float (&v)[NV], uint32_t &bits, uint32_t &f1) {
+        lds_read_vec<NV>(rd_data + slot, v);
+        if constexpr (NV == 16) bits = lds_read<uint16_t>(rd_bits + slot);
+        else bits = (uint32_t)lds_read<uint8_t>(rd_bits + slot);
+        f1 = lds_read<uint32_t>(rd_f1 + slot);
+    };
+    const int bshift = NV == 16 ? 0 : k0 & 7;
+    auto exchange = [&](uint32_t par_off, float own_min, float edge, float &omin, float &oedge) {
+        typedef volatile f2 __attribute__((address_space(3))) *xp;
+        f2 v = {own_min, edge};
+        *(xp)(uintptr_t)(xw + par_off) = v;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const f2 o = lds_read<f2>(xr + par_off);
+        omin = o.x;
+        oedge = o.y;
+    };
+
+    // ---- path head: dst = src, Lp = src
+    float Lp[NV];
+    load_vec<NV>(reinterpret_cast<const float *>(src_b + vo_out), Lp);
+    store_vec<NV>(reinterpret_cast<float *>(dst_b + vo_out), Lp);
+    float lmin = Lp[0];
+#pragma unroll
+    for (int j = 1; j < NV; j++) lmin = fminf(lmin, Lp[j]);
+    float minLp, oedge;
+    {
+        const float own = wave_min(lmin);
+        float omin;
+        exchange(0u, own, half ? Lp[0] : Lp[NV - 1], omin, oedge);
+        minLp = fminf(own, omin);
+    }
+    if (LEN < 2) return;
+
+    for (int t = 1; t < RS && t < LEN; t++)
+        issue_fill(src_b + (ptrdiff_t)t * vstep, rec_b + (ptrdiff_t)t * rstep, (uint32_t)(t & (RS - 1)) * C::SLOT_B);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float ca[NV], cb[NV];
+    uint32_t ba, fa, bb = 0, fb = 0;
+    read_slot(1u * C::SLOT_B, ca, ba, fa);
+
+    // one path pixel: costs/record of this pixel in (cur, cbits, cf1); the next pixel's are fetched into
+    // (nxt, nbits, nf1). FILL / NEXT: the fill RS-1 pixels ahead / the next pixel exist.
+    auto pixel = [&](int s, uint32_t par_off, bool FILL, bool NEXT, const float (&cur)[NV], uint32_t cbits, uint32_t cf1,
+                     float (&nxt)[NV], uint32_t &nbits, uint32_t &nf1) {
+        if (FILL) {
+            const int t = s + RS - 1;
+            issue_fill(src_b + (ptrdiff_t)t * vstep, rec_b + (ptrdiff_t)t * rstep, (uint32_t)(t & (RS - 1)) * C::SLOT_B);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::WAITN) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (NEXT) {
+            read_slot((uint32_t)((s + 1) & (RS - 1)) * C::SLOT_B, nxt, nbits, nf1);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NV; j++) nxt[j] = 0.0f;
+            nbits = 0; nf1 = 0;
+        }
+        const bool d1hi = cf1 & 1u;
+        const uint32_t kbits = cbits >> bshift;
+        const float P1a = d1hi ? sp.P1[1] : sp.P1[0], P1b = d1hi ? sp.P1[2] : sp.P1[1];
+        const float P2a = d1hi ? sp.P2[1] : sp.P2[0], P2b = d1hi ? sp.P2[2] : sp.P2[1];
+        float up = dpp_f<0x138>(ADC_LARGE_F, Lp[NV - 1]);   // wave_shr:1 -> Lp[k0-1]
+        float dn = dpp_f<0x130>(ADC_LARGE_F, Lp[0]);        // wave_shl:1 -> Lp[k0+NV]
+        if (half) up = lane == 0 ? oedge : up;
+        else dn = lane == 63 ? oedge : dn;
+        const float l4a = minLp + P2a, l4b = minLp + P2b;
+        float nw[NV];
+        float lm = ADC_LARGE_F;
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            const bool hi = (kbits >> j) & 1u;
+            const float P1 = hi ? P1b : P1a;
+            const float l1 = Lp[j];
+            const float l2 = (j == 0 ? up : Lp[j - 1]) + P1;
+            const float l3 = (j == NV - 1 ? dn : Lp[j + 1]) + P1;
+            const float l4 = hi ? l4b : l4a;
+            const float m = fminf(fminf(l1, l2), fminf(l3, l4));
+            nw[j] = (cur[j] + m) / 2.0f;
+            lm = fminf(lm, nw[j]);
+        }
+        store_vec<NV>(reinterpret_cast<float *>(dst_b + (ptrdiff_t)s * vstep + vo_out), nw);
+#pragma unroll
+        for (int j = 0; j < NV; j++) Lp[j] = nw[j];
+        const float own = wave_min(lm);
+        float omin;
+        exchange(par_off, own, half ? Lp[0] : Lp[NV - 1], omin, oedge);
+        minLp = fminf(own, omin);
+    };
+
+    int s = 1;
+    // main part: every fill and every next pixel exists (s + 1 + RS - 1 < LEN for the second pixel of a trip)
+    for (; s + RS < LEN; s += 2) {
+        pixel(s, 1024u, true, true, ca, ba, fa, cb, bb, fb);
+        pixel(s + 1, 0u, true, true, cb, bb, fb, ca, ba, fa);
+    }
+    for (; s < LEN; s++) {
+        pixel(s, (uint32_t)(s & 1) * 1024u, s + RS - 1 < LEN, s + 1 < LEN, ca, ba, fa, cb, bb, fb);
+#pragma unroll
+        for (int j = 0; j < NV; j++) ca[j] = cb[j];
+        ba = bb; fa = fb;
+    }
+}
+
 template <int NVW>
 static void launch_split(const float *src, float *dst, const Planes &p, const Geom &g, const ScanParams &sp,
                          int vertical, int forward, hipStream_t s) {
     typedef ScanCfgSplit<NVW> C;
     const int nlines = vertical ? g.W : g.H;
-    const size_t lds = (size_t)2 * C::RS * C::SLOT_B + 64;
     const uint32_t *rec = vertical ? p.rec_v : (forward ? p.rec_hf : p.rec_hb);
+    static const int version = std::getenv("ADC_SPLIT_VERSION") ? std::atoi(std::getenv("ADC_SPLIT_VERSION")) : 2;
+    if (version >= 2) {
+        const size_t lds = (size_t)2 * C::RS * C::SLOT_B + 2048;
+        if (vertical)
+            k_scanline_split2<NVW, 1><<<dim3(nlines), dim3(128), lds, s>>>(src, dst, rec, g.W, g.H, g.Dp, forward, sp);
+        else
+            k_scanline_split2<NVW, 0><<<dim3(nlines), dim3(128), lds, s>>>(src, dst, rec, g.W, g.H, g.Dp, forward, sp);
+        return;
+    }
+    const size_t lds = (size_t)2 * C::RS * C::SLOT_B + 64;
     if (vertical)
         k_scanline_split<NVW, 1><<<dim3(nlines), dim3(128), lds, s>>>(src, dst, rec, g.W, g.H, g.Dp, forward, sp);
     else
