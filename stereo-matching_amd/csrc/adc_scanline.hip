@@ -20,6 +20,7 @@
 // by LDS-DMA into a per-wave ring RS pixels ahead of their use, with counted vmcnt waits.
 #include "adc_common.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -206,7 +207,7 @@ __device__ __forceinline__ void lds_read_vec(uint32_t byte_off, float (&v)[NV]) 
     }
 }
 
-template <int NV, bool WTA> struct ScanCfg {
+template <int NV, bool WTA, int RSO = 0> struct ScanCfg {
     static constexpr int DATA_B = 256 * NV;                         // one pixel's cost vector
     static constexpr int FLAG_B = ((8 * NV + 4 + 15) / 16) * 16;    // its colour-step record, padded to 16 B
     static constexpr int SLOT_B = DATA_B + FLAG_B;
@@ -215,7 +216,7 @@ template <int NV, bool WTA> struct ScanCfg {
     static constexpr int OPS = NDMA + 1 + NST;                      // vector-memory operations per path pixel
     static constexpr int RS_MEM = NV <= 4 ? 16 : (NV == 8 ? 8 : 4); // ring slots per wave that fit ~17 KB
     static constexpr int RS_CNT = 63 / OPS + 2;                     // ... and that keep the counted wait within 6 bits
-    static constexpr int RS = RS_MEM < RS_CNT ? RS_MEM : RS_CNT;
+    static constexpr int RS = RSO ? RSO : (RS_MEM < RS_CNT ? RS_MEM : RS_CNT);   // RSO: ring size chosen by the caller
     // operations younger than the fill of step s+1 at the point step s waits for it (see the loop)
     static constexpr int WAITN = (RS - 2) * OPS;
     static_assert(WAITN <= 63 && RS >= 3, "vmcnt is a 6-bit counter");
@@ -239,18 +240,14 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 // WTA: this is the last pass; while a pixel's final costs are still in registers, also write its
 //      left-view winner-take-all disparity with the sub-pixel fit (ComputeDisparityCuda,
 //      ADC/ADCensusStereo.cu:200-267): first strict minimum over d, invalid (+inf) at either end of the range.
-template <int NV, int VERT, bool FULL, bool WTA>
-__global__ void __launch_bounds__(256)
-k_scanline(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ rec,
-           float *__restrict__ disp, int W, int H, int dmin, int D, int Dp, int forward, ScanParams sp) {
-    typedef ScanCfg<NV, WTA> C;
-    extern __shared__ __align__(16) uint8_t lds_raw[];
+// One wavefront, one scanline: `line` is the row / column, `ring` this wave's RS x SLOT_B bytes of LDS.
+template <int NV, int VERT, bool FULL, bool WTA, int RSO = 0>
+__device__ __forceinline__ void
+scan_wave(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ rec,
+          float *__restrict__ disp, int W, int H, int dmin, int D, int Dp, int forward, const ScanParams &sp,
+          int line, uint8_t *ring) {
+    typedef ScanCfg<NV, WTA, RSO> C;
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int line = blockIdx.x * 4 + wave;
-    const int nlines = VERT ? W : H;
-    if (line >= nlines) return;
-    uint8_t *ring = lds_raw + (size_t)wave * C::RS * C::SLOT_B;
     const int LEN = VERT ? H : W;
     const int dir = forward ? 1 : -1;
     const int k0 = lane * NV;
@@ -420,16 +417,30 @@ k_scanline(const float *__restrict__ src, float *__restrict__ dst, const uint32_
     }
 }
 
-// ---- two wavefronts per scanline ------------------------------------------------------------------------
-// A pass is a serial chain per scanline, and a horizontal pass over 1080 rows has barely one wavefront
-// per SIMD to run it: every dependent instruction then waits out its full latency. Here a scanline is
-// shared by the two waves of a 128-thread workgroup, each holding half of the disparities (NVW per
-// lane). Per path pixel they exchange, through LDS and one barrier, what crosses the middle: their
-// partial minimum of Lr(p-r, .) and the one cost next to the other half (Lr(p-r, D/2-1) / Lr(p-r, D/2)).
-// min() is exact and commutative, so the results are the same bits as the one-wave kernel's.
-// Only for Dp == D == 128*NVW, passes without the fused WTA.
-template <int NVW> struct ScanCfgSplit {
-    static constexpr int NVF = 2 * NVW;                               // disparities per lane pair = the record's NV
+template <int NV, int VERT, bool FULL, bool WTA>
+__global__ void __launch_bounds__(256)
+k_scanline(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ rec,
+           float *__restrict__ disp, int W, int H, int dmin, int D, int Dp, int forward, ScanParams sp) {
+    typedef ScanCfg<NV, WTA> C;
+    extern __shared__ __align__(16) uint8_t lds_raw[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int line = blockIdx.x * 4 + wave;
+    if (line >= (VERT ? W : H)) return;
+    scan_wave<NV, VERT, FULL, WTA>(src, dst, rec, disp, W, H, dmin, D, Dp, forward, sp, line,
+                                   lds_raw + (size_t)wave * C::RS * C::SLOT_B);
+}
+
+// ---- several wavefronts per scanline --------------------------------------------------------------------
+// A pass is a serial chain per scanline. One wave per scanline is the cheapest way to run it, but the wave
+// count then has to fit the chip: a SIMD that gets a second full-width wave needs twice as long per path
+// pixel, and the pass lasts as long as its slowest scanline (1024 rows: 0.83 ms, 1080 rows: 1.19 ms on 1024
+// SIMDs). Here a scanline is shared by the NPARTS = 2 or 4 waves of a workgroup, each holding a contiguous
+// share of the disparities (NVW per lane). Per path pixel they exchange, through LDS and one barrier, what
+// crosses the seams: their partial minima of Lr(p-r, .) and the costs next to a neighbour's share. min() is
+// exact and commutative, so the results are the same bits as the one-wave kernel's.
+// Only for Dp == D == NPARTS*64*NVW, passes without the fused WTA.
+template <int NVW, int NPARTS = 2> struct ScanCfgSplit {
+    static constexpr int NVF = NPARTS * NVW;                          // disparities per lane over all the scanline's waves = the record's NV
     static constexpr int DATA_B = 256 * NVW;                          // this wave's half of a pixel's cost vector
     static constexpr int FLAG_B = ((8 * NVF + 4 + 15) / 16) * 16;     // the pixel's colour-step record (both halves)
     static constexpr int SLOT_B = DATA_B + FLAG_B;
@@ -443,149 +454,8 @@ template <int NVW> struct ScanCfgSplit {
     static_assert(WAITN <= 63 && RS >= 3, "vmcnt is a 6-bit counter");
 };
 
-template <int NVW, int VERT>
-__global__ void __launch_bounds__(128)
-k_scanline_split(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ rec,
-                 int W, int H, int Dp, int forward, ScanParams sp) {
-    typedef ScanCfgSplit<NVW> C;
-    constexpr int NV = NVW;
-    extern __shared__ __align__(16) uint8_t lds_raw[];
-    const int lane = threadIdx.x & 63;
-    const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0: low disparities, 1: high
-    const int line = blockIdx.x;
-    uint8_t *ring = lds_raw + (size_t)half * C::RS * C::SLOT_B;
-    const uint32_t xch_off = (uint32_t)(uintptr_t)(lds_raw + (size_t)2 * C::RS * C::SLOT_B);   // [parity][half] x {min, edge}
-    const int LEN = VERT ? H : W;
-    const int dir = forward ? 1 : -1;
-    const int kbase = half * 64 * NV;             // first disparity of this wave
-    const int k0 = kbase + lane * NV;
-    const int recw = 2 * C::NVF + 1;
-    const int x0 = VERT ? line : (forward ? 0 : W - 1);
-    const int y0 = VERT ? (forward ? 0 : H - 1) : line;
-    const ptrdiff_t pstep = VERT ? (ptrdiff_t)dir * W : (ptrdiff_t)dir;
-    const ptrdiff_t pix0 = (ptrdiff_t)y0 * W + x0;
-    const ptrdiff_t rshift = (VERT && !forward) ? (ptrdiff_t)W : 0;
-
-    const float *gfill = src + kbase + (NV >= 4 ? 4 * lane : lane);
-    const uint32_t *gflag = rec + lane;
-    const bool flag_lane = lane < recw;
-    auto issue_fill = [&](int s) {
-        const ptrdiff_t p = pix0 + (ptrdiff_t)s * pstep;
-        uint8_t *slot = ring + (s % C::RS) * C::SLOT_B;
-        const float *g = gfill + (size_t)p * Dp;
-#pragma unroll
-        for (int q = 0; q < C::NDMA; q++) {
-            if constexpr (NV >= 4)
-                __builtin_amdgcn_global_load_lds(g + q * 256, (lds_void *)(slot + q * 1024), 16, 0, 0);
-            else
-                __builtin_amdgcn_global_load_lds(g + q * 64, (lds_void *)(slot + q * 256), 4, 0, 0);
-        }
-        if (flag_lane)
-            __builtin_amdgcn_global_load_lds(gflag + (size_t)(p + rshift) * recw, (lds_void *)(slot + C::DATA_B), 4, 0, 0);
-    };
-    const uint32_t ring_off = (uint32_t)(uintptr_t)ring;
-    auto read_slot = [&](int s, float (&v)[NV], uint32_t &bits, uint32_t &f1) {
-        const uint32_t slot = ring_off + (uint32_t)(s % C::RS) * C::SLOT_B;
-        lds_read_vec<NV>(slot + (uint32_t)(lane * NV) * 4, v);
-        if constexpr (NV == 16) bits = lds_read<uint16_t>(slot + C::DATA_B + (k0 >> 3));
-        else bits = (uint32_t)lds_read<uint8_t>(slot + C::DATA_B + (k0 >> 3));
-        f1 = lds_read<uint32_t>(slot + C::DATA_B + 8 * C::NVF);
-    };
-    const int bshift = NV == 16 ? 0 : k0 & 7;
-    // hand {own minimum, own cost next to the other half} over, get the other wave's pair
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    const int edge_lane = half ? 0 : 63;
-    auto exchange = [&](int par, float own_min, float edge, float &omin, float &oedge) {
-        if (lane == edge_lane) {
-            typedef volatile f2 __attribute__((address_space(3))) *xp;
-            f2 v = {own_min, edge};
-            *(xp)(uintptr_t)(xch_off + (uint32_t)(par * 2 + half) * 8) = v;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const f2 o = lds_read<f2>(xch_off + (uint32_t)(par * 2 + (1 - half)) * 8);
-        omin = o.x;
-        oedge = o.y;
-    };
-
-    // ---- path head: dst = src, Lp = src
-    float Lp[NV];
-    load_vec<NV>(src + (size_t)pix0 * Dp + k0, Lp);
-    store_vec<NV>(dst + (size_t)pix0 * Dp + k0, Lp);
-    float lmin = Lp[0];
-#pragma unroll
-    for (int j = 1; j < NV; j++) lmin = fminf(lmin, Lp[j]);
-    float minLp, oedge;
-    {
-        const float own = wave_min(lmin);
-        float omin;
-        exchange(0, own, half ? Lp[0] : Lp[NV - 1], omin, oedge);
-        minLp = fminf(own, omin);
-    }
-    if (LEN < 2) return;
-
-    for (int t = 1; t < C::RS && t < LEN; t++) issue_fill(t);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    float cur[NV];
-    uint32_t cbits, cf1;
-    read_slot(1, cur, cbits, cf1);
-
-    float *outp = dst + (size_t)(pix0 + pstep) * Dp + k0;
-    const ptrdiff_t ostep = pstep * (ptrdiff_t)Dp;
-    for (int s = 1; s < LEN; s++) {
-        const int t = s + C::RS - 1;
-        if (t < LEN) issue_fill(t);
-        if (t < LEN) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::WAITN) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        float nxt[NV];
-        uint32_t nbits = 0, nf1 = 0;
-#pragma unroll
-        for (int j = 0; j < NV; j++) nxt[j] = 0.0f;
-        if (s + 1 < LEN) read_slot(s + 1, nxt, nbits, nf1);
-        const bool d1hi = cf1 & 1u;
-        const uint32_t kbits = cbits >> bshift;
-        const float P1a = d1hi ? sp.P1[1] : sp.P1[0], P1b = d1hi ? sp.P1[2] : sp.P1[1];
-        const float P2a = d1hi ? sp.P2[1] : sp.P2[0], P2b = d1hi ? sp.P2[2] : sp.P2[1];
-        // neighbours across lanes; at the seam between the two waves the value the other wave handed over,
-        // at the ends of the disparity range the reference's Large_Float sentinels
-        float up = dpp_f<0x138>(ADC_LARGE_F, Lp[NV - 1]);   // wave_shr:1 -> Lp[k0-1]
-        float dn = dpp_f<0x130>(ADC_LARGE_F, Lp[0]);        // wave_shl:1 -> Lp[k0+NV]
-        if (half) up = lane == 0 ? oedge : up;
-        else dn = lane == 63 ? oedge : dn;
-        const float l4a = minLp + P2a, l4b = minLp + P2b;
-        float nw[NV];
-        float lm = ADC_LARGE_F;
-#pragma unroll
-        for (int j = 0; j < NV; j++) {
-            const bool hi = (kbits >> j) & 1u;
-            const float P1 = hi ? P1b : P1a;
-            const float l1 = Lp[j];
-            const float l2 = (j == 0 ? up : Lp[j - 1]) + P1;
-            const float l3 = (j == NV - 1 ? dn : Lp[j + 1]) + P1;
-            const float l4 = hi ? l4b : l4a;
-            const float m = fminf(fminf(l1, l2), fminf(l3, l4));
-            nw[j] = (cur[j] + m) / 2.0f;
-            lm = fminf(lm, nw[j]);
-        }
-        store_vec<NV>(outp, nw);
-        outp += ostep;
-#pragma unroll
-        for (int j = 0; j < NV; j++) Lp[j] = nw[j];
-        {
-            const float own = wave_min(lm);
-            float omin;
-            exchange(s & 1, own, half ? Lp[0] : Lp[NV - 1], omin, oedge);
-            minLp = fminf(own, omin);
-        }
-#pragma unroll
-        for (int j = 0; j < NV; j++) cur[j] = nxt[j];
-        cbits = nbits;
-        cf1 = nf1;
-    }
-}
-
-// The same pass with the per-pixel instruction count cut down (a wave issues at most one instruction
-// per 4-cycle turn, and with ~2 waves per SIMD nothing else fills the turns it wastes):
+// The per-pixel instruction count is kept down (a wave issues at most one instruction per 4-cycle turn,
+// and with ~2 waves per SIMD nothing else fills the turns it wastes):
 //   * the path pointers live in scalar registers and advance by scalar adds; fills, the record fetch and
 //     the store address memory as scalar base + 32-bit lane offset,
 //   * the LDS-DMA pieces of one pixel share one M0 value (the instruction offset moves both addresses),
@@ -593,28 +463,39 @@ k_scanline_split(const float *__restrict__ src, float *__restrict__ dst, const u
 //     exchange parity is static and the "next pixel" registers swap roles instead of being copied,
 //   * every lane writes {wave minimum, its own boundary cost} to its own exchange slot; the other wave
 //     reads the slot of the lane next to the seam -- no execution-mask juggling around the LDS write.
-template <int NVW, int VERT>
-__global__ void __launch_bounds__(128)
-k_scanline_split2(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ rec,
-                  int W, int H, int Dp, int forward, ScanParams sp) {
-    typedef ScanCfgSplit<NVW> C;
+// NPARTS = 2 or 4 waves share the scanline `line`; this is wave `part` of them (its disparities:
+// part*64*NVW ...). lds0: LDS byte offset of the scanline's area = NPARTS rings of RS x SLOT_B bytes, then
+// the exchange area [parity][part][lane] x XB bytes. With four parts a wave needs the minima of the three
+// others and one boundary cost from each neighbour: every lane writes {wave minimum, its lowest cost, its
+// highest cost}, and the readers pick lane 63 of the wave below and lane 0 of the wave above.
+template <int NVW, int NPARTS, int VERT>
+__device__ __forceinline__ void
+scan_split_wave(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ rec,
+                int W, int H, int Dp, int forward, const ScanParams &sp, int line, int part, uint32_t lds0) {
+    typedef ScanCfgSplit<NVW, NPARTS> C;
     constexpr int NV = NVW;
     constexpr int RS = C::RS;
     static_assert((RS & (RS - 1)) == 0, "ring size must be a power of two");
+    static_assert(NPARTS == 2 || NPARTS == 4, "two or four waves per scanline");
     typedef float f2 __attribute__((ext_vector_type(2)));
-    extern __shared__ __align__(16) uint8_t lds_raw[];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    constexpr uint32_t XB = NPARTS == 2 ? 8u : 16u;              // bytes per lane slot of the exchange area
+    constexpr uint32_t XPAR = NPARTS * 64u * XB;                 // bytes per parity
     const int lane = threadIdx.x & 63;
-    const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0: low disparities, 1: high
-    const int line = blockIdx.x;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)lds_raw;
-    const uint32_t ring_off = lds0 + (uint32_t)half * RS * C::SLOT_B;
-    // exchange area: [parity][half][lane] x {wave minimum, boundary cost}
-    const uint32_t xch = lds0 + 2u * RS * C::SLOT_B;
-    const uint32_t xw = xch + (uint32_t)half * 512u + (uint32_t)lane * 8u;
-    const uint32_t xr = xch + (uint32_t)(1 - half) * 512u + (half ? 63u : 0u) * 8u;   // the other wave's lane at the seam
+    const int half = part;                                       // (two parts: 0 = low disparities, 1 = high)
+    const uint32_t ring_off = lds0 + (uint32_t)part * RS * C::SLOT_B;
+    const uint32_t xch = lds0 + (uint32_t)NPARTS * RS * C::SLOT_B;
+    const uint32_t xw = xch + (uint32_t)part * 64u * XB + (uint32_t)lane * XB;
+    // two parts: the other wave's lane at the seam. Four parts: lane 63 of the wave below, lane 0 of the
+    // wave above, lane 0 of the remaining one (indices wrap; what the end parts read there is discarded).
+    const uint32_t xr = NPARTS == 2 ? xch + (uint32_t)(1 - part) * 64u * XB + (part ? 63u : 0u) * XB
+                                    : xch + (uint32_t)((part + NPARTS - 1) % NPARTS) * 64u * XB + 63u * XB;
+    const uint32_t xr_up = xch + (uint32_t)((part + 1) % NPARTS) * 64u * XB;
+    const uint32_t xr_far = xch + (uint32_t)((part + 2) % NPARTS) * 64u * XB;
+    const bool has_below = part > 0, has_above = part < NPARTS - 1;
     const int LEN = VERT ? H : W;
     const int dir = forward ? 1 : -1;
-    const int kbase = half * 64 * NV;             // first disparity of this wave
+    const int kbase = part * 64 * NV;             // first disparity of this wave
     const int k0 = kbase + lane * NV;
     const int recw = 2 * C::NVF + 1;
     const int x0 = VERT ? line : (forward ? 0 : W - 1);
@@ -659,15 +540,33 @@ k_scanline_split2(const float *__restrict__ src, float *__restrict__ dst, const 
         f1 = lds_read<uint32_t>(rd_f1 + slot);
     };
     const int bshift = NV == 16 ? 0 : k0 & 7;
-    auto exchange = [&](uint32_t par_off, float own_min, float edge, float &omin, float &oedge) {
-        typedef volatile f2 __attribute__((address_space(3))) *xp;
-        f2 v = {own_min, edge};
-        *(xp)(uintptr_t)(xw + par_off) = v;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const f2 o = lds_read<f2>(xr + par_off);
-        omin = o.x;
-        oedge = o.y;
+    // in: this wave's minimum and its lanes' lowest / highest cost. out: the minimum over the other waves,
+    // and the costs just below this wave's first / just above its last disparity (Large_Float at the ends of
+    // the range; with two parts only the one at the seam is meaningful, the other is not used).
+    auto exchange = [&](uint32_t par, float own_min, float lo, float hi, float &omin, float &e_below, float &e_above) {
+        if constexpr (NPARTS == 2) {
+            typedef volatile f2 __attribute__((address_space(3))) *xp;
+            f2 v = {own_min, half ? lo : hi};
+            *(xp)(uintptr_t)(xw + par * XPAR) = v;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const f2 o = lds_read<f2>(xr + par * XPAR);
+            omin = o.x;
+            e_below = o.y;
+            e_above = o.y;
+        } else {
+            typedef volatile f4 __attribute__((address_space(3))) *xp;
+            f4 v = {own_min, lo, hi, 0.0f};
+            *(xp)(uintptr_t)(xw + par * XPAR) = v;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const f4 a = lds_read<f4>(xr + par * XPAR);        // wave below: {min, ., highest}
+            const f4 b = lds_read<f4>(xr_up + par * XPAR);     // wave above: {min, lowest, .}
+            const float c = lds_read<float>(xr_far + par * XPAR);
+            omin = fminf(fminf(a.x, b.x), c);
+            e_below = has_below ? a.z : ADC_LARGE_F;
+            e_above = has_above ? b.y : ADC_LARGE_F;
+        }
     };
 
     // ---- path head: dst = src, Lp = src
@@ -677,11 +576,11 @@ k_scanline_split2(const float *__restrict__ src, float *__restrict__ dst, const 
     float lmin = Lp[0];
 #pragma unroll
     for (int j = 1; j < NV; j++) lmin = fminf(lmin, Lp[j]);
-    float minLp, oedge;
+    float minLp, e_below, e_above;
     {
         const float own = wave_min(lmin);
         float omin;
-        exchange(0u, own, half ? Lp[0] : Lp[NV - 1], omin, oedge);
+        exchange(0u, own, Lp[0], Lp[NV - 1], omin, e_below, e_above);
         minLp = fminf(own, omin);
     }
     if (LEN < 2) return;
@@ -695,7 +594,7 @@ k_scanline_split2(const float *__restrict__ src, float *__restrict__ dst, const 
 
     // one path pixel: costs/record of this pixel in (cur, cbits, cf1); the next pixel's are fetched into
     // (nxt, nbits, nf1). FILL / NEXT: the fill RS-1 pixels ahead / the next pixel exist.
-    auto pixel = [&](int s, uint32_t par_off, bool FILL, bool NEXT, const float (&cur)[NV], uint32_t cbits, uint32_t cf1,
+    auto pixel = [&](int s, uint32_t par, bool FILL, bool NEXT, const float (&cur)[NV], uint32_t cbits, uint32_t cf1,
                      float (&nxt)[NV], uint32_t &nbits, uint32_t &nf1) {
         if (FILL) {
             const int t = s + RS - 1;
@@ -717,8 +616,13 @@ k_scanline_split2(const float *__restrict__ src, float *__restrict__ dst, const 
         const float P2a = d1hi ? sp.P2[1] : sp.P2[0], P2b = d1hi ? sp.P2[2] : sp.P2[1];
         float up = dpp_f<0x138>(ADC_LARGE_F, Lp[NV - 1]);   // wave_shr:1 -> Lp[k0-1]
         float dn = dpp_f<0x130>(ADC_LARGE_F, Lp[0]);        // wave_shl:1 -> Lp[k0+NV]
-        if (half) up = lane == 0 ? oedge : up;
-        else dn = lane == 63 ? oedge : dn;
+        if constexpr (NPARTS == 2) {
+            if (half) up = lane == 0 ? e_below : up;
+            else dn = lane == 63 ? e_above : dn;
+        } else {
+            up = lane == 0 ? e_below : up;
+            dn = lane == 63 ? e_above : dn;
+        }
         const float l4a = minLp + P2a, l4b = minLp + P2b;
         float nw[NV];
         float lm = ADC_LARGE_F;
@@ -739,44 +643,73 @@ k_scanline_split2(const float *__restrict__ src, float *__restrict__ dst, const 
         for (int j = 0; j < NV; j++) Lp[j] = nw[j];
         const float own = wave_min(lm);
         float omin;
-        exchange(par_off, own, half ? Lp[0] : Lp[NV - 1], omin, oedge);
+        exchange(par, own, Lp[0], Lp[NV - 1], omin, e_below, e_above);
         minLp = fminf(own, omin);
     };
 
     int s = 1;
     // main part: every fill and every next pixel exists (s + 1 + RS - 1 < LEN for the second pixel of a trip)
     for (; s + RS < LEN; s += 2) {
-        pixel(s, 1024u, true, true, ca, ba, fa, cb, bb, fb);
+        pixel(s, 1u, true, true, ca, ba, fa, cb, bb, fb);
         pixel(s + 1, 0u, true, true, cb, bb, fb, ca, ba, fa);
     }
     for (; s < LEN; s++) {
-        pixel(s, (uint32_t)(s & 1) * 1024u, s + RS - 1 < LEN, s + 1 < LEN, ca, ba, fa, cb, bb, fb);
+        pixel(s, (uint32_t)(s & 1), s + RS - 1 < LEN, s + 1 < LEN, ca, ba, fa, cb, bb, fb);
 #pragma unroll
         for (int j = 0; j < NV; j++) ca[j] = cb[j];
         ba = bb; fa = fb;
     }
 }
 
+template <int NVW, int NPARTS> constexpr size_t scan_split_lds() {
+    typedef ScanCfgSplit<NVW, NPARTS> C;
+    return (size_t)NPARTS * C::RS * C::SLOT_B + 2u * NPARTS * 64u * (NPARTS == 2 ? 8u : 16u);
+}
+
+template <int NVW, int VERT>
+__global__ void __launch_bounds__(128)
+k_scanline_split2(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ rec,
+                  int W, int H, int Dp, int forward, ScanParams sp) {
+    extern __shared__ __align__(16) uint8_t lds_raw[];
+    const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    scan_split_wave<NVW, 2, VERT>(src, dst, rec, W, H, Dp, forward, sp, blockIdx.x, part, (uint32_t)(uintptr_t)lds_raw);
+}
+
+// Horizontal pass over slightly more rows than the chip has SIMDs (1080 rows, 1024 SIMDs): a second
+// full-width wave on a SIMD doubles that SIMD's per-pixel time and with it the whole pass. The first
+// `rows_main` rows (a multiple of 4, at most one per SIMD) run one wave each; every remaining row is
+// shared by the four waves of its own workgroup, 64 disparities each, which adds only a light wave to
+// the SIMDs it lands on. Dp == D == 256 only (NV = 4 for the main rows, one disparity per lane for the rest).
+#ifndef HYB_RS
+#define HYB_RS 8
+#endif
+__global__ void __launch_bounds__(256)
+k_scanline_hybrid(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ rec,
+                  int W, int H, int Dp, int forward, ScanParams sp, int rows_main) {
+    typedef ScanCfg<4, false, HYB_RS> C;
+    extern __shared__ __align__(16) uint8_t lds_raw[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int main_wgs = rows_main >> 2;
+    if ((int)blockIdx.x < main_wgs) {
+        scan_wave<4, 0, true, false, HYB_RS>(src, dst, rec, nullptr, W, H, 0, Dp, Dp, forward, sp, blockIdx.x * 4 + wave,
+                                     lds_raw + (size_t)wave * C::RS * C::SLOT_B);
+    } else {
+        __builtin_amdgcn_s_setprio(2);   // the row's four waves wait for each other every pixel: let them go first
+        scan_split_wave<1, 4, 0>(src, dst, rec, W, H, Dp, forward, sp, rows_main + ((int)blockIdx.x - main_wgs), wave,
+                                 (uint32_t)(uintptr_t)lds_raw);
+    }
+}
+
 template <int NVW>
 static void launch_split(const float *src, float *dst, const Planes &p, const Geom &g, const ScanParams &sp,
                          int vertical, int forward, hipStream_t s) {
-    typedef ScanCfgSplit<NVW> C;
     const int nlines = vertical ? g.W : g.H;
     const uint32_t *rec = vertical ? p.rec_v : (forward ? p.rec_hf : p.rec_hb);
-    static const int version = std::getenv("ADC_SPLIT_VERSION") ? std::atoi(std::getenv("ADC_SPLIT_VERSION")) : 2;
-    if (version >= 2) {
-        const size_t lds = (size_t)2 * C::RS * C::SLOT_B + 2048;
-        if (vertical)
-            k_scanline_split2<NVW, 1><<<dim3(nlines), dim3(128), lds, s>>>(src, dst, rec, g.W, g.H, g.Dp, forward, sp);
-        else
-            k_scanline_split2<NVW, 0><<<dim3(nlines), dim3(128), lds, s>>>(src, dst, rec, g.W, g.H, g.Dp, forward, sp);
-        return;
-    }
-    const size_t lds = (size_t)2 * C::RS * C::SLOT_B + 64;
+    const size_t lds = scan_split_lds<NVW, 2>();
     if (vertical)
-        k_scanline_split<NVW, 1><<<dim3(nlines), dim3(128), lds, s>>>(src, dst, rec, g.W, g.H, g.Dp, forward, sp);
+        k_scanline_split2<NVW, 1><<<dim3(nlines), dim3(128), lds, s>>>(src, dst, rec, g.W, g.H, g.Dp, forward, sp);
     else
-        k_scanline_split<NVW, 0><<<dim3(nlines), dim3(128), lds, s>>>(src, dst, rec, g.W, g.H, g.Dp, forward, sp);
+        k_scanline_split2<NVW, 0><<<dim3(nlines), dim3(128), lds, s>>>(src, dst, rec, g.W, g.H, g.Dp, forward, sp);
 }
 
 template <int NV, bool WTA>
@@ -803,13 +736,46 @@ static void launch_nv(const float *src, float *dst, float *disp, const Planes &p
 #undef ADC_SCAN
 }
 
+static int env_int(const char *name, int dflt) {
+    const char *v = std::getenv(name);
+    return v ? std::atoi(v) : dflt;
+}
+
 void launch_scanline_pass(const float *src, float *dst, const Planes &p, const Geom &g,
                           const ScanParams &sp, int vertical, int forward, float *disp_wta, hipStream_t s) {
-    // two waves per scanline where a pass has too few scanlines to fill the SIMDs: horizontal passes
-    // (ADC_SCAN_SPLIT: 0 never, 1 horizontal passes, 2 every pass without the fused WTA)
-    static const int split_env = std::getenv("ADC_SCAN_SPLIT") ? std::atoi(std::getenv("ADC_SCAN_SPLIT")) : 1;
+    // How a pass is spread over the chip (ADC_SCAN_SPLIT: 0 one wave per scanline always; 1 automatic; 2 two
+    // waves per scanline wherever the kernel allows; ADC_SCAN_HYBRID=0 takes the mixed launch out of 1).
+    // Automatic, horizontal passes only -- a vertical pass has a scanline per column, plenty for the SIMDs:
+    //   rows <= SIMDs                 one wave per row (the pass then runs at the HBM ceiling);
+    //   SIMDs < rows <= 1.5 x SIMDs   mixed launch: one wave per row for `rows_main` rows, four light waves
+    //                                 for each remaining row (1080 rows on 1024 SIMDs: 3.77 -> 3.45 ms for
+    //                                 the four passes); rows_main = max(3/4 SIMDs, 2 rows - 3/2 SIMDs), the
+    //                                 best of the values measured at 1080, 1200 and 1440 rows;
+    //   more rows, or D = 512         two waves per row.
+    const int split_env = env_int("ADC_SCAN_SPLIT", 1);
     const bool split_ok = !disp_wta && g.Dp == g.D && (g.NV == 4 || g.NV == 8) && g.D == 64 * g.NV;
-    if (split_ok && (split_env >= 2 || (split_env == 1 && !vertical))) {
+    bool split = split_ok && split_env >= 2;
+    if (split_ok && split_env == 1 && !vertical) {
+        static const int simds = [] {
+            int dev = 0, cus = 0;
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+                return 0;
+            return 4 * cus;
+        }();
+        split = g.H > simds;
+        if (split && g.NV == 4 && simds >= 16 && g.H <= simds + simds / 2 && env_int("ADC_SCAN_HYBRID", 1)) {
+            typedef ScanCfg<4, false, HYB_RS> C;
+            int rows_main = std::max(simds / 4 * 3, 2 * g.H - simds / 2 * 3);
+            rows_main = env_int("ADC_HYB_MAIN", rows_main);
+            rows_main = std::min(std::min(rows_main, simds), g.H - 1) & ~3;
+            const size_t lds_main = (size_t)4 * C::RS * C::SLOT_B, lds_rest = scan_split_lds<1, 4>();
+            k_scanline_hybrid<<<dim3(rows_main / 4 + (g.H - rows_main)), dim3(256), std::max(lds_main, lds_rest), s>>>(
+                src, dst, forward ? p.rec_hf : p.rec_hb, g.W, g.H, g.Dp, forward, sp, rows_main);
+            return;
+        }
+    }
+    if (split) {
         if (g.NV == 4) launch_split<2>(src, dst, p, g, sp, vertical, forward, s);
         else launch_split<4>(src, dst, p, g, sp, vertical, forward, s);
         return;

@@ -161,6 +161,34 @@ def test_aggregated_volume_midsize(pkg, orc, synth):
         assert same(got[k], want[k]), describe(k, got[k], want[k])
 
 
+def _scan_volume_and_map_match(pkg, orc, L, R, D):
+    H, W = L.shape[:2]
+    h = pkg.ADCensusStereo(0)
+    assert h.Initialize(W, H, pkg.ADCensusOption(max_disparity=D)), h.last_error()
+    disp = h.match(L, R)
+    vol = h.get_buffer("cost_scan")
+    h.close()
+    want, taps = orc.match(L, R, orc.default_option(max_disparity=D), want=["cost_scan"])
+    assert same(vol, taps["cost_scan"]), describe("cost_scan", vol, taps["cost_scan"])
+    assert same(disp, want), describe("disp_final", disp, want)
+
+
+@pytest.mark.parametrize("W,H", [(96, 1100), (33, 1500), (24, 1600)])
+def test_more_rows_than_simds(pkg, orc, synth, W, H):
+    """Tall, narrow frames with 256 disparities: horizontal passes over more rows than the chip has SIMDs take
+    the mixed launch (one wave per row + four waves per row) or, from 1.5x the SIMD count, two waves per row; the final volume must still be the oracle's bits."""
+    L, R, _ = synth.pair(81, 256, H, 256)
+    _scan_volume_and_map_match(pkg, orc, np.ascontiguousarray(L[:, :W]), np.ascontiguousarray(R[:, :W]), 256)
+
+
+@pytest.mark.parametrize("mode", ["0", "2"])
+def test_scanline_wave_layouts(pkg, orc, synth, monkeypatch, mode):
+    """ADC_SCAN_SPLIT=0: one wave per scanline in every pass; 2: two waves per scanline in every pass that allows it."""
+    monkeypatch.setenv("ADC_SCAN_SPLIT", mode)
+    L, R, _ = synth.pair(82, 200, 120, 256)
+    _scan_volume_and_map_match(pkg, orc, L, R, 256)
+
+
 def test_direct_aggregation_kernel(pkg, orc, synth, monkeypatch):
     monkeypatch.setenv("ADC_AGG_VARIANT", "1")
     L, R, _ = synth.pair(23, 170, 90, 70)
