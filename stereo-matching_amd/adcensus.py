@@ -245,6 +245,8 @@ class ADCensusStereo:
 def match_batch(lefts, rights, option, devices):
     """adc_match_batch: pair i runs on devices[i % len(devices)]. Returns the list of disparity maps."""
     n = len(lefts)
+    if n == 0:
+        return []
     H, W = lefts[0].shape[:2]
     lefts = [np.ascontiguousarray(a, np.uint8) for a in lefts]
     rights = [np.ascontiguousarray(a, np.uint8) for a in rights]

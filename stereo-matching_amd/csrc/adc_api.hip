@@ -57,6 +57,9 @@ struct adc_handle {
     float *newval = nullptr;
     uint32_t *tile_stamp = nullptr; // per 8x8 tile: stamp of the last voting pass that filled a pixel in it
     uint32_t vote_stamp = 16;       // first stamp of the next frame (stamps only grow, the array is never cleared)
+    // second set of staging buffers of the pipelined batch path (allocated on first use)
+    uint8_t *pipe_h_l = nullptr, *pipe_h_r = nullptr, *pipe_d_l = nullptr, *pipe_d_r = nullptr;
+    float *pipe_h_o = nullptr, *pipe_d_o[2] = {nullptr, nullptr};
     uint32_t *list3_mis = nullptr, *list3_occ = nullptr;   // with list2_*: ping-pong lists of the entries still open between voting passes
     short *binmap = nullptr;       // histogram bin of every pixel of the current disparity map (voting), -1 = none
     // debug snapshots
@@ -118,6 +121,7 @@ void release(adc_handle *h) {
     h->events.clear();
     if (h->stream) { hipStreamDestroy(h->stream); h->stream = nullptr; }
     h->snap_init = h->snap_aggr = nullptr;
+    h->pipe_d_o[0] = h->pipe_d_o[1] = nullptr;
     h->initialized = false;
     h->have_times = false;
 }
@@ -586,6 +590,101 @@ int adc_get_buffer(adc_handle *h, adc_buffer_id id, void *dst, size_t bytes) {
     return ADC_OK;
 }
 
+}  // extern "C" (reopened below)
+
+namespace {
+
+// One device's share of a batch (pairs first, first + stride, ...), pipelined: while the GPU matches pair k
+// the host thread copies pair k+1 into pinned memory and queues its upload, and pair k-1's result travels
+// back and is copied out. Two slots of staging buffers; three streams (upload, the handle's compute stream,
+// download) ordered by events. Per frame the GPU then sees only its own 13 ms, not the 2 x 6.2 MB in and
+// 8.3 MB out that a synchronous adc_match adds in front of and behind them.
+int run_pipelined(adc_handle *h, const adc_batch_desc *d, int first, int stride) {
+    const size_t npx = (size_t)h->g.W * h->g.H;
+    HIPCHK(h, hipSetDevice(h->device));
+    struct Slot {
+        uint8_t *h_l = nullptr, *h_r = nullptr, *d_l = nullptr, *d_r = nullptr;
+        float *h_o = nullptr, *d_o = nullptr;
+        hipEvent_t in = nullptr, done = nullptr, out = nullptr;
+        int pair = -1;
+    } slot[2];
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    int rc = ADC_OK;
+    auto cleanup = [&]() {
+        if (s_in) hipStreamDestroy(s_in);
+        if (s_out) hipStreamDestroy(s_out);
+        for (Slot &q : slot) {
+            if (q.in) hipEventDestroy(q.in);
+            if (q.done) hipEventDestroy(q.done);
+            if (q.out) hipEventDestroy(q.out);
+        }
+    };
+#define PIPE(call)                                             \
+    do {                                                       \
+        hipError_t e_ = (call);                                \
+        if (e_ != hipSuccess) { cleanup(); return h->fail_hip(#call, e_); } \
+    } while (0)
+    PIPE(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
+    PIPE(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
+    // slot 0 reuses the handle's own staging buffers; slot 1 gets a second set (kept by the handle)
+    slot[0].h_l = h->h_bgr_l; slot[0].h_r = h->h_bgr_r; slot[0].h_o = h->h_disp;
+    slot[0].d_l = h->d_bgr_l; slot[0].d_r = h->d_bgr_r;
+    if (!h->pipe_d_o[0]) {
+        if ((rc = dev_alloc(h, &h->pipe_d_o[0], npx)) || (rc = dev_alloc(h, &h->pipe_d_o[1], npx)) ||
+            (rc = dev_alloc(h, &h->pipe_d_l, npx * 3)) || (rc = dev_alloc(h, &h->pipe_d_r, npx * 3)) ||
+            (rc = host_alloc(h, &h->pipe_h_l, npx * 3)) || (rc = host_alloc(h, &h->pipe_h_r, npx * 3)) ||
+            (rc = host_alloc(h, &h->pipe_h_o, npx))) { cleanup(); return rc; }
+    }
+    slot[0].d_o = h->pipe_d_o[0];
+    slot[1].h_l = h->pipe_h_l; slot[1].h_r = h->pipe_h_r; slot[1].h_o = h->pipe_h_o;
+    slot[1].d_l = h->pipe_d_l; slot[1].d_r = h->pipe_d_r; slot[1].d_o = h->pipe_d_o[1];
+    for (Slot &q : slot) {
+        PIPE(hipEventCreateWithFlags(&q.in, hipEventDisableTiming));
+        PIPE(hipEventCreateWithFlags(&q.done, hipEventDisableTiming));
+        PIPE(hipEventCreateWithFlags(&q.out, hipEventDisableTiming));
+    }
+    auto finish = [&](Slot &q) -> int {   // pair q.pair: wait for its download, hand the map to the caller
+        if (q.pair < 0) return ADC_OK;
+        hipError_t e = hipEventSynchronize(q.out);
+        if (e != hipSuccess) return h->fail_hip("hipEventSynchronize", e);
+        std::memcpy(d->disp_left[q.pair], q.h_o, npx * sizeof(float));
+        q.pair = -1;
+        return ADC_OK;
+    };
+    int k = 0;
+    for (int i = first; i < d->n_pairs; i += stride, k++) {
+        Slot &q = slot[k & 1];
+        // the slot's previous pair (k-2) was finished at the end of iteration k-1, so every buffer of it is free
+        if (!d->left_bgr[i] || !d->right_bgr[i] || !d->disp_left[i]) { rc = h->fail(ADC_ERR_ARG, "adc_match_batch: null pointer in pair " + std::to_string(i)); break; }
+        std::memcpy(q.h_l, d->left_bgr[i], npx * 3);
+        std::memcpy(q.h_r, d->right_bgr[i], npx * 3);
+        PIPE(hipMemcpyAsync(q.d_l, q.h_l, npx * 3, hipMemcpyHostToDevice, s_in));
+        PIPE(hipMemcpyAsync(q.d_r, q.h_r, npx * 3, hipMemcpyHostToDevice, s_in));
+        PIPE(hipEventRecord(q.in, s_in));
+        PIPE(hipStreamWaitEvent(h->stream, q.in, 0));
+        if ((rc = enqueue_match(h, q.d_l, q.d_r, q.d_o, h->stream)) != ADC_OK) break;
+        PIPE(hipEventRecord(q.done, h->stream));
+        PIPE(hipStreamWaitEvent(s_out, q.done, 0));
+        PIPE(hipMemcpyAsync(q.h_o, q.d_o, npx * sizeof(float), hipMemcpyDeviceToHost, s_out));
+        PIPE(hipEventRecord(q.out, s_out));
+        q.pair = i;
+        // while the GPU works on pair k, hand back pair k-1
+        if ((rc = finish(slot[(k + 1) & 1])) != ADC_OK) break;
+    }
+    if (rc == ADC_OK) rc = finish(slot[(k + 1) & 1]);
+    if (rc == ADC_OK) rc = finish(slot[k & 1]);
+    hipStreamSynchronize(s_in);
+    hipStreamSynchronize(h->stream);
+    hipStreamSynchronize(s_out);
+#undef PIPE
+    cleanup();
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
 int adc_match_batch(const adc_batch_desc *d) {
     if (!d || d->n_pairs < 0 || d->n_devices <= 0 || !d->devices || (d->n_pairs > 0 && (!d->left_bgr || !d->right_bgr || !d->disp_left))) {
         g_thread_error = "adc_match_batch: bad descriptor";
@@ -600,8 +699,7 @@ int adc_match_batch(const adc_batch_desc *d) {
             adc_handle *h = adc_create(d->devices[di]);
             if (!h) { rcs[di] = ADC_ERR_NOMEM; errs[di] = "adc_create failed"; return; }
             int rc = adc_initialize(h, d->width, d->height, &d->option);
-            for (int i = di; rc == ADC_OK && i < d->n_pairs; i += nd)
-                rc = adc_match(h, d->left_bgr[i], d->right_bgr[i], d->disp_left[i]);
+            if (rc == ADC_OK) rc = run_pipelined(h, d, di, nd);
             if (rc != ADC_OK) { rcs[di] = rc; errs[di] = h->err; }
             adc_destroy(h);
         });

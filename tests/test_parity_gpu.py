@@ -245,10 +245,15 @@ def test_match_device_and_batch(pkg, orc, synth):
     t = h.stage_times()
     assert t["total"] > 0 and abs(sum(t[k] for k in ("pre", "cost", "aggr", "scan", "wta", "refine")) - t["total"]) < 0.05 * t["total"] + 0.05
     h.close()
-    pairs = [synth.pair(50 + i, 128, 64, 32)[:2] for i in range(3)]
-    disps = pkg.match_batch([p[0] for p in pairs], [p[1] for p in pairs], pkg.ADCensusOption(max_disparity=32), [0])
-    for (l, r), d in zip(pairs, disps):
-        assert same(d, orc.match(l, r, orc.default_option(max_disparity=32))[0])
+    # the batch path pipelines uploads, matches and downloads over two staging slots: 5 pairs on one handle
+    # reuse each slot at least twice; [0, 0] runs two such pipelines side by side on the same GPU
+    pairs = [synth.pair(50 + i, 128, 64, 32)[:2] for i in range(5)]
+    wants = [orc.match(l, r, orc.default_option(max_disparity=32))[0] for l, r in pairs]
+    for devices in ([0], [0, 0]):
+        disps = pkg.match_batch([p[0] for p in pairs], [p[1] for p in pairs], pkg.ADCensusOption(max_disparity=32), devices)
+        for d, w in zip(disps, wants):
+            assert same(d, w)
+    assert pkg.match_batch([], [], pkg.ADCensusOption(max_disparity=32), [0]) == []
 
 
 def test_cpp_shim_program(pkg, orc, synth, tmp_path):
