@@ -122,6 +122,13 @@ void launch_clear_masks(uint8_t *occ, uint8_t *mis, uint32_t *counters, size_t n
 // its previous turn. Stamps grow monotonically over frames (stamp0 = this frame's pass 0), so the tile
 // array is never cleared.
 #define VOTE_ROWS 8
+// Most pixels of a support region carry the same one or two disparities, so the 64 lanes of a histogram
+// update mostly hit one LDS word and are served one after the other. VOTE_COPIES histograms, one per
+// lane & (VOTE_COPIES - 1), with an odd stride (different banks for the same bin) cut that serialisation;
+// the copies are summed when the histogram is read out. Counts are integers: any order is exact.
+#ifndef VOTE_COPIES
+#define VOTE_COPIES 4
+#endif
 #ifndef VOTE_TILE_SHIFT
 #define VOTE_TILE_SHIFT 3
 #endif
@@ -135,6 +142,7 @@ k_vote(const float *__restrict__ disp, const short *__restrict__ binmap, const u
        int tau_s, float tau_h, int cap, int tiles_w, uint32_t stamp0, int pass) {
     extern __shared__ int hist[];
     const int lane = threadIdx.x;
+    const int hstride = D | 1, hcopy = (lane & (VOTE_COPIES - 1)) * hstride;
     const uint32_t n = *count;
     for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
         const uint32_t p = list[e];
@@ -157,7 +165,7 @@ k_vote(const float *__restrict__ disp, const short *__restrict__ binmap, const u
             }
         }
         if (todo) {
-            for (int k = lane; k < D; k += 64) hist[k] = 0;
+            for (int k = lane; k < VOTE_COPIES * hstride; k += 64) hist[k] = 0;
             __syncthreads();
             const int top = (a >> 16) & 0xff, bot = a >> 24;
             const int nrows = top + bot + 1;
@@ -189,11 +197,11 @@ k_vote(const float *__restrict__ disp, const short *__restrict__ binmap, const u
                     }
 #pragma unroll
                     for (int u = 0; u < VOTE_ROWS; u++)
-                        if (ba[u] >= 0) atomicAdd(&hist[ba[u]], 1);
+                        if (ba[u] >= 0) atomicAdd(&hist[hcopy + ba[u]], 1);
                     if (any_b) {
 #pragma unroll
                         for (int u = 0; u < VOTE_ROWS; u++)
-                            if (bb[u] >= 0) atomicAdd(&hist[bb[u]], 1);
+                            if (bb[u] >= 0) atomicAdd(&hist[hcopy + bb[u]], 1);
                     }
                 }
             }
@@ -201,7 +209,9 @@ k_vote(const float *__restrict__ disp, const short *__restrict__ binmap, const u
             // first bin holding the maximum count, and the total
             int mh = 0, mk = 0x7fffffff, cnt = 0;
             for (int k = lane; k < D; k += 64) {
-                const int h = hist[k];
+                int h = hist[k];
+#pragma unroll
+                for (int c = 1; c < VOTE_COPIES; c++) h += hist[c * hstride + k];
                 if (mh < h) { mh = h; mk = k; }
                 cnt += h;
             }
@@ -275,7 +285,7 @@ void launch_region_voting_pass(float *disp, short *binmap, uint8_t *mask, const 
                                float *newval, const uint32_t *arms, uint32_t *tile_stamp, uint32_t stamp0, int pass,
                                int cap, const Geom &g, int tau_s, float tau_h, hipStream_t s) {
     const int tw = vote_tiles_w(g.W);
-    k_vote<<<dim3(8192), dim3(64), (size_t)g.D * sizeof(int), s>>>(disp, binmap, mask, list, count, newval, arms,
+    k_vote<<<dim3(8192), dim3(64), (size_t)VOTE_COPIES * (g.D | 1) * sizeof(int), s>>>(disp, binmap, mask, list, count, newval, arms,
                                                                   tile_stamp, g.W, g.dmin, g.D, tau_s, tau_h, cap, tw,
                                                                   stamp0, pass);
     k_apply<<<dim3(512), dim3(256), 0, s>>>(disp, binmap, mask, list, count, newval, out_list, out_count, tile_stamp,
@@ -340,14 +350,18 @@ k_interp(const float *__restrict__ disp, const uint8_t *__restrict__ occ, const 
     extern __shared__ uint32_t s_off[];              // LDS_TAB: 16 x maxlen offsets
     const uint32_t n_mis = counters[0], n_occ = counters[1];
     const uint32_t n = n_mis + n_occ;
+    if (blockIdx.x * (256u / 16u) >= n) return;      // nothing listed for this workgroup: skip the table set-up too
     const int s = threadIdx.x & 15;                  // this lane's direction
     const double *dy = ray_dy + (size_t)s * maxlen;
     const double *dx = ray_dx + (size_t)s * maxlen;
     const uint32_t *off = ray_off + (size_t)s * maxlen;
     if (LDS_TAB) {
-        for (int i = threadIdx.x; i < 16 * maxlen; i += 256) s_off[i] = ray_off[i];
+        // row stride maxlen | 1: the 16 lanes of a pixel read the same column of 16 different rows, and with
+        // a stride that is a multiple of 64 dwords (maxlen = 256) all of those sit in one LDS bank
+        const int lstride = maxlen | 1;
+        for (int i = threadIdx.x; i < 16 * maxlen; i += 256) s_off[(i / maxlen) * lstride + (i % maxlen)] = ray_off[i];
         __syncthreads();
-        off = s_off + s * maxlen;
+        off = s_off + s * lstride;
     }
     const uint32_t per_block = 256 / 16;
     for (uint32_t e0 = blockIdx.x * per_block; e0 < n; e0 += gridDim.x * per_block) {
@@ -441,7 +455,7 @@ void launch_interpolate(float *disp, const uint8_t *occ, const uint8_t *mis,
     const size_t npx = (size_t)g.W * g.H;
     hipMemsetAsync(counters + 2, 0, 2 * sizeof(uint32_t), s);
     k_compact<<<dim3(1024), dim3(1024), 0, s>>>(list_mis, list_occ, mis, occ, list2_mis, list2_occ, counters);
-    const size_t tab = (size_t)16 * maxlen * sizeof(uint32_t);
+    const size_t tab = (size_t)16 * (maxlen | 1) * sizeof(uint32_t);
 #define ADC_INTERP(I, L, LDS) k_interp<I, L><<<dim3(8192), dim3(256), LDS, s>>>( \
         disp, occ, mis, list2_mis, list2_occ, counters + 2, newval, pix_l, ray_dy, ray_dx, ray_off, g.W, g.H, maxlen, npx)
     if (!ray_off) ADC_INTERP(false, false, 0);
