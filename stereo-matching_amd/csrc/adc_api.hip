@@ -695,6 +695,7 @@ int adc_match_batch(const adc_batch_desc *d) {
     std::vector<std::string> errs(nd);
     std::vector<std::thread> threads;
     for (int di = 0; di < nd; di++) {
+        if (di >= d->n_pairs) break;   // fewer pairs than devices: the rest would only allocate and free
         threads.emplace_back([&, di]() {
             adc_handle *h = adc_create(d->devices[di]);
             if (!h) { rcs[di] = ADC_ERR_NOMEM; errs[di] = "adc_create failed"; return; }
