@@ -151,6 +151,19 @@ __device__ __forceinline__ float wave_min(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// v_min without the canonicalising v_max the compiler puts in front of fminf() operands it cannot prove to be
+// quiet: no value in these kernels is ever a NaN (finite costs and the Large_Float sentinel only).
+__device__ __forceinline__ float min_raw(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float min3_raw(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 template <int NV>
 __device__ __forceinline__ void load_vec(const float *p, float (&v)[NV]) {
     if constexpr (NV == 1) {
@@ -382,18 +395,19 @@ scan_wave(const float *__restrict__ src, float *__restrict__ dst, const uint32_t
         const float P2a = d1hi ? sp.P2[1] : sp.P2[0], P2b = d1hi ? sp.P2[2] : sp.P2[1];
         const float up = dpp_f<0x138>(ADC_LARGE_F, Lp[NV - 1]);  // wave_shr:1 -> Lp[k0-1]
         const float dn = dpp_f<0x130>(ADC_LARGE_F, Lp[0]);       // wave_shl:1 -> Lp[k0+NV]
-        const float l4a = minLp + P2a, l4b = minLp + P2b;
+        float l4a = minLp + P2a, l4b = minLp + P2b;
+        asm volatile("" : "+v"(l4a), "+v"(l4b));   // keep the two sums: selecting the penalty first costs an addition per disparity
         float nw[NV];
         float lm = ADC_LARGE_F;
 #pragma unroll
         for (int j = 0; j < NV; j++) {
             const bool hi = (kbits >> j) & 1u;
             const float P1 = hi ? P1b : P1a;
+            // min(a + P1, b + P1) == min(a, b) + P1 bit for bit (rounding is monotonic), one addition less
             const float l1 = Lp[j];
-            const float l2 = (j == 0 ? up : Lp[j - 1]) + P1;
-            const float l3 = (j == NV - 1 ? dn : Lp[j + 1]) + P1;
+            const float l23 = min_raw(j == 0 ? up : Lp[j - 1], j == NV - 1 ? dn : Lp[j + 1]) + P1;
             const float l4 = hi ? l4b : l4a;
-            const float m = fminf(fminf(l1, l2), fminf(l3, l4));
+            const float m = min3_raw(l1, l23, l4);
             const float v = (cur[j] + m) / 2.0f;
             nw[j] = (FULL || (active && k0 + j < D)) ? v : ADC_LARGE_F;
             lm = fminf(lm, nw[j]);
@@ -623,18 +637,19 @@ scan_split_wave(const float *__restrict__ src, float *__restrict__ dst, const ui
             up = lane == 0 ? e_below : up;
             dn = lane == 63 ? e_above : dn;
         }
-        const float l4a = minLp + P2a, l4b = minLp + P2b;
+        float l4a = minLp + P2a, l4b = minLp + P2b;
+        asm volatile("" : "+v"(l4a), "+v"(l4b));   // keep the two sums: selecting the penalty first costs an addition per disparity
         float nw[NV];
         float lm = ADC_LARGE_F;
 #pragma unroll
         for (int j = 0; j < NV; j++) {
             const bool hi = (kbits >> j) & 1u;
             const float P1 = hi ? P1b : P1a;
+            // min(a + P1, b + P1) == min(a, b) + P1 bit for bit (rounding is monotonic), one addition less
             const float l1 = Lp[j];
-            const float l2 = (j == 0 ? up : Lp[j - 1]) + P1;
-            const float l3 = (j == NV - 1 ? dn : Lp[j + 1]) + P1;
+            const float l23 = min_raw(j == 0 ? up : Lp[j - 1], j == NV - 1 ? dn : Lp[j + 1]) + P1;
             const float l4 = hi ? l4b : l4a;
-            const float m = fminf(fminf(l1, l2), fminf(l3, l4));
+            const float m = min3_raw(l1, l23, l4);
             nw[j] = (cur[j] + m) / 2.0f;
             lm = fminf(lm, nw[j]);
         }
