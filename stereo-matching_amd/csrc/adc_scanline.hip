@@ -490,10 +490,10 @@ scan_split_wave(const float *__restrict__ src, float *__restrict__ dst, const ui
     constexpr int NV = NVW;
     constexpr int RS = C::RS;
     static_assert((RS & (RS - 1)) == 0, "ring size must be a power of two");
-    static_assert(NPARTS == 2 || NPARTS == 4, "two or four waves per scanline");
+    static_assert(NPARTS == 1 || NPARTS == 2 || NPARTS == 4, "one, two or four waves per scanline");
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef float f4 __attribute__((ext_vector_type(4)));
-    constexpr uint32_t XB = NPARTS == 2 ? 8u : 16u;              // bytes per lane slot of the exchange area
+    constexpr uint32_t XB = NPARTS == 4 ? 16u : 8u;              // bytes per lane slot of the exchange area
     constexpr uint32_t XPAR = NPARTS * 64u * XB;                 // bytes per parity
     const int lane = threadIdx.x & 63;
     const int half = part;                                       // (two parts: 0 = low disparities, 1 = high)
@@ -558,7 +558,11 @@ scan_split_wave(const float *__restrict__ src, float *__restrict__ dst, const ui
     // and the costs just below this wave's first / just above its last disparity (Large_Float at the ends of
     // the range; with two parts only the one at the seam is meaningful, the other is not used).
     auto exchange = [&](uint32_t par, float own_min, float lo, float hi, float &omin, float &e_below, float &e_above) {
-        if constexpr (NPARTS == 2) {
+        if constexpr (NPARTS == 1) {          // the wave holds the whole disparity range: nothing to exchange
+            omin = own_min;
+            e_below = ADC_LARGE_F;
+            e_above = ADC_LARGE_F;
+        } else if constexpr (NPARTS == 2) {
             typedef volatile f2 __attribute__((address_space(3))) *xp;
             f2 v = {own_min, half ? lo : hi};
             *(xp)(uintptr_t)(xw + par * XPAR) = v;
@@ -630,7 +634,9 @@ scan_split_wave(const float *__restrict__ src, float *__restrict__ dst, const ui
         const float P2a = d1hi ? sp.P2[1] : sp.P2[0], P2b = d1hi ? sp.P2[2] : sp.P2[1];
         float up = dpp_f<0x138>(ADC_LARGE_F, Lp[NV - 1]);   // wave_shr:1 -> Lp[k0-1]
         float dn = dpp_f<0x130>(ADC_LARGE_F, Lp[0]);        // wave_shl:1 -> Lp[k0+NV]
-        if constexpr (NPARTS == 2) {
+        if constexpr (NPARTS == 1) {
+            // the DPP shifts already put Large_Float at both ends of the range
+        } else if constexpr (NPARTS == 2) {
             if (half) up = lane == 0 ? e_below : up;
             else dn = lane == 63 ? e_above : dn;
         } else {
@@ -678,7 +684,7 @@ scan_split_wave(const float *__restrict__ src, float *__restrict__ dst, const ui
 
 template <int NVW, int NPARTS> constexpr size_t scan_split_lds() {
     typedef ScanCfgSplit<NVW, NPARTS> C;
-    return (size_t)NPARTS * C::RS * C::SLOT_B + 2u * NPARTS * 64u * (NPARTS == 2 ? 8u : 16u);
+    return (size_t)NPARTS * C::RS * C::SLOT_B + (NPARTS == 1 ? 0u : 2u * NPARTS * 64u * (NPARTS == 2 ? 8u : 16u));
 }
 
 template <int NVW, int VERT>
@@ -688,6 +694,21 @@ k_scanline_split2(const float *__restrict__ src, float *__restrict__ dst, const 
     extern __shared__ __align__(16) uint8_t lds_raw[];
     const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     scan_split_wave<NVW, 2, VERT>(src, dst, rec, W, H, Dp, forward, sp, blockIdx.x, part, (uint32_t)(uintptr_t)lds_raw);
+}
+
+// One wave per scanline with the lean loop of scan_split_wave (NPARTS = 1): every pass without the fused WTA whose
+// disparity count fills the lanes exactly (Dp == D == 64*NV, NV <= 8). Four scanlines per workgroup.
+template <int NV, int VERT>
+__global__ void __launch_bounds__(256)
+k_scanline_lean(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ rec,
+                int W, int H, int Dp, int forward, ScanParams sp) {
+    typedef ScanCfgSplit<NV, 1> C;
+    extern __shared__ __align__(16) uint8_t lds_raw[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int line = blockIdx.x * 4 + wave;
+    if (line >= (VERT ? W : H)) return;
+    scan_split_wave<NV, 1, VERT>(src, dst, rec, W, H, Dp, forward, sp, line, 0,
+                                 (uint32_t)(uintptr_t)lds_raw + (uint32_t)wave * C::RS * C::SLOT_B);
 }
 
 // Horizontal pass over slightly more rows than the chip has SIMDs (1080 rows, 1024 SIMDs): a second
@@ -793,6 +814,31 @@ void launch_scanline_pass(const float *src, float *dst, const Planes &p, const G
     if (split) {
         if (g.NV == 4) launch_split<2>(src, dst, p, g, sp, vertical, forward, s);
         else launch_split<4>(src, dst, p, g, sp, vertical, forward, s);
+        return;
+    }
+    if (!disp_wta && g.Dp == g.D && g.D == 64 * g.NV && g.NV <= 8 && env_int("ADC_SCAN_LEAN", 1)) {
+        const int nlines = vertical ? g.W : g.H;
+        const uint32_t *rec = vertical ? p.rec_v : (forward ? p.rec_hf : p.rec_hb);
+        dim3 grid((nlines + 3) / 4), block(256);
+#define ADC_LEAN(N)                                                                                                         \
+    do {                                                                                                                    \
+        const size_t lds = 4 * scan_split_lds<N, 1>();                                                                      \
+        static bool attr_set = false;                                                                                       \
+        if (!attr_set) {                                                                                                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scanline_lean<N, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scanline_lean<N, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+            attr_set = true;                                                                                                \
+        }                                                                                                                   \
+        if (vertical) k_scanline_lean<N, 1><<<grid, block, lds, s>>>(src, dst, rec, g.W, g.H, g.Dp, forward, sp);           \
+        else k_scanline_lean<N, 0><<<grid, block, lds, s>>>(src, dst, rec, g.W, g.H, g.Dp, forward, sp);                    \
+    } while (0)
+        switch (g.NV) {
+            case 1: ADC_LEAN(1); break;
+            case 2: ADC_LEAN(2); break;
+            case 4: ADC_LEAN(4); break;
+            default: ADC_LEAN(8); break;
+        }
+#undef ADC_LEAN
         return;
     }
 #define ADC_NV(N)                                                                    \
