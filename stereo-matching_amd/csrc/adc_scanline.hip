@@ -453,17 +453,17 @@ k_scanline(const float *__restrict__ src, float *__restrict__ dst, const uint32_
 // crosses the seams: their partial minima of Lr(p-r, .) and the costs next to a neighbour's share. min() is
 // exact and commutative, so the results are the same bits as the one-wave kernel's.
 // Only for Dp == D == NPARTS*64*NVW, passes without the fused WTA.
-template <int NVW, int NPARTS = 2> struct ScanCfgSplit {
+template <int NVW, int NPARTS = 2, bool WTA = false> struct ScanCfgSplit {
     static constexpr int NVF = NPARTS * NVW;                          // disparities per lane over all the scanline's waves = the record's NV
     static constexpr int DATA_B = 256 * NVW;                          // this wave's half of a pixel's cost vector
     static constexpr int FLAG_B = ((8 * NVF + 4 + 15) / 16) * 16;     // the pixel's colour-step record (both halves)
     static constexpr int SLOT_B = DATA_B + FLAG_B;
     static constexpr int NDMA = NVW >= 4 ? NVW / 4 : NVW;
-    static constexpr int NST = NVW >= 4 ? NVW / 4 : 1;
+    static constexpr int NST = (NVW >= 4 ? NVW / 4 : 1) + (WTA ? 1 : 0);
     static constexpr int OPS = NDMA + 1 + NST;
     static constexpr int RS_MEM = NVW <= 4 ? 16 : 8;
     static constexpr int RS_CNT = 63 / OPS + 2;
-    static constexpr int RS = RS_MEM < RS_CNT ? RS_MEM : RS_CNT;
+    static constexpr int RS = (RS_MEM <= RS_CNT) ? RS_MEM : (RS_CNT >= 8 ? 8 : 4);   // a power of two (slots are masked)
     static constexpr int WAITN = (RS - 2) * OPS;
     static_assert(WAITN <= 63 && RS >= 3, "vmcnt is a 6-bit counter");
 };
@@ -482,11 +482,15 @@ template <int NVW, int NPARTS = 2> struct ScanCfgSplit {
 // the exchange area [parity][part][lane] x XB bytes. With four parts a wave needs the minima of the three
 // others and one boundary cost from each neighbour: every lane writes {wave minimum, its lowest cost, its
 // highest cost}, and the readers pick lane 63 of the wave below and lane 0 of the wave above.
-template <int NVW, int NPARTS, int VERT>
+// WTA (one wave per scanline only): the pass is the last one and also writes the left-view winner-take-all
+// disparity of every pixel, as scan_wave does.
+template <int NVW, int NPARTS, int VERT, bool WTA = false>
 __device__ __forceinline__ void
 scan_split_wave(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ rec,
-                int W, int H, int Dp, int forward, const ScanParams &sp, int line, int part, uint32_t lds0) {
-    typedef ScanCfgSplit<NVW, NPARTS> C;
+                int W, int H, int Dp, int forward, const ScanParams &sp, int line, int part, uint32_t lds0,
+                float *__restrict__ disp = nullptr, int dmin = 0) {
+    typedef ScanCfgSplit<NVW, NPARTS, WTA> C;
+    static_assert(!WTA || NPARTS == 1, "the fused WTA needs a pixel's whole disparity range in one wave");
     constexpr int NV = NVW;
     constexpr int RS = C::RS;
     static_assert((RS & (RS - 1)) == 0, "ring size must be a power of two");
@@ -587,6 +591,29 @@ scan_split_wave(const float *__restrict__ src, float *__restrict__ dst, const ui
         }
     };
 
+    // c[] = a pixel's final costs, cmin = their minimum (ComputeDisparityCuda, ADC/ADCensusStereo.cu:200-267)
+    const int D = Dp;
+    auto write_wta = [&](const float (&c)[NV], float cmin, ptrdiff_t pixel) {
+        int kk = 0x7fffffff;
+#pragma unroll
+        for (int j = NV - 1; j >= 0; j--) kk = (c[j] == cmin) ? k0 + j : kk;   // first disparity of this lane at the minimum
+        const int best = wave_min_i32(kk);                                      // first over the wave
+        float out = __int_as_float(0x7f800000);                                 // Invalid_Float
+        if (best > 0 && best < D - 1 && cmin < ADC_LARGE_F) {
+            const int l1 = (best - 1) / NV, e1 = (best - 1) - l1 * NV;
+            const int l2 = (best + 1) / NV, e2 = (best + 1) - l2 * NV;
+            float s1 = c[0], s2 = c[0];
+#pragma unroll
+            for (int j = 1; j < NV; j++) { s1 = (e1 == j) ? c[j] : s1; s2 = (e2 == j) ? c[j] : s2; }
+            const float c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s1), l1));
+            const float c2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s2), l2));
+            const float fb = (float)(best + dmin);
+            const float denom = c1 + c2 - 2 * cmin;
+            out = (denom != 0.0f) ? fb + (c1 - c2) / (denom * 2.0f) : fb;
+        }
+        if (lane == 0) disp[pixel] = out;
+    };
+
     // ---- path head: dst = src, Lp = src
     float Lp[NV];
     load_vec<NV>(reinterpret_cast<const float *>(src_b + vo_out), Lp);
@@ -601,6 +628,7 @@ scan_split_wave(const float *__restrict__ src, float *__restrict__ dst, const ui
         exchange(0u, own, Lp[0], Lp[NV - 1], omin, e_below, e_above);
         minLp = fminf(own, omin);
     }
+    if constexpr (WTA) write_wta(Lp, minLp, pix0);
     if (LEN < 2) return;
 
     for (int t = 1; t < RS && t < LEN; t++)
@@ -666,6 +694,7 @@ scan_split_wave(const float *__restrict__ src, float *__restrict__ dst, const ui
         float omin;
         exchange(par, own, Lp[0], Lp[NV - 1], omin, e_below, e_above);
         minLp = fminf(own, omin);
+        if constexpr (WTA) write_wta(Lp, minLp, pix0 + (ptrdiff_t)s * pstep);
     };
 
     int s = 1;
@@ -698,17 +727,17 @@ k_scanline_split2(const float *__restrict__ src, float *__restrict__ dst, const 
 
 // One wave per scanline with the lean loop of scan_split_wave (NPARTS = 1): every pass without the fused WTA whose
 // disparity count fills the lanes exactly (Dp == D == 64*NV, NV <= 8). Four scanlines per workgroup.
-template <int NV, int VERT>
+template <int NV, int VERT, bool WTA>
 __global__ void __launch_bounds__(256)
 k_scanline_lean(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ rec,
-                int W, int H, int Dp, int forward, ScanParams sp) {
-    typedef ScanCfgSplit<NV, 1> C;
+                float *__restrict__ disp, int W, int H, int dmin, int Dp, int forward, ScanParams sp) {
+    typedef ScanCfgSplit<NV, 1, WTA> C;
     extern __shared__ __align__(16) uint8_t lds_raw[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int line = blockIdx.x * 4 + wave;
     if (line >= (VERT ? W : H)) return;
-    scan_split_wave<NV, 1, VERT>(src, dst, rec, W, H, Dp, forward, sp, line, 0,
-                                 (uint32_t)(uintptr_t)lds_raw + (uint32_t)wave * C::RS * C::SLOT_B);
+    scan_split_wave<NV, 1, VERT, WTA>(src, dst, rec, W, H, Dp, forward, sp, line, 0,
+                                      (uint32_t)(uintptr_t)lds_raw + (uint32_t)wave * C::RS * C::SLOT_B, disp, dmin);
 }
 
 // Horizontal pass over slightly more rows than the chip has SIMDs (1080 rows, 1024 SIMDs): a second
@@ -816,21 +845,25 @@ void launch_scanline_pass(const float *src, float *dst, const Planes &p, const G
         else launch_split<4>(src, dst, p, g, sp, vertical, forward, s);
         return;
     }
-    if (!disp_wta && g.Dp == g.D && g.D == 64 * g.NV && g.NV <= 8 && env_int("ADC_SCAN_LEAN", 1)) {
+    if (g.Dp == g.D && g.D == 64 * g.NV && g.NV <= 8 && env_int("ADC_SCAN_LEAN", 1)) {
         const int nlines = vertical ? g.W : g.H;
         const uint32_t *rec = vertical ? p.rec_v : (forward ? p.rec_hf : p.rec_hb);
         dim3 grid((nlines + 3) / 4), block(256);
-#define ADC_LEAN(N)                                                                                                         \
+#define ADC_LEAN_K(N, V, T)                                                                                                 \
     do {                                                                                                                    \
-        const size_t lds = 4 * scan_split_lds<N, 1>();                                                                      \
+        typedef ScanCfgSplit<N, 1, T> CL;                                                                                   \
+        const size_t lds = (size_t)4 * CL::RS * CL::SLOT_B;                                                                 \
         static bool attr_set = false;                                                                                       \
         if (!attr_set) {                                                                                                    \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scanline_lean<N, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scanline_lean<N, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scanline_lean<N, V, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
             attr_set = true;                                                                                                \
         }                                                                                                                   \
-        if (vertical) k_scanline_lean<N, 1><<<grid, block, lds, s>>>(src, dst, rec, g.W, g.H, g.Dp, forward, sp);           \
-        else k_scanline_lean<N, 0><<<grid, block, lds, s>>>(src, dst, rec, g.W, g.H, g.Dp, forward, sp);                    \
+        k_scanline_lean<N, V, T><<<grid, block, lds, s>>>(src, dst, rec, disp_wta, g.W, g.H, g.dmin, g.Dp, forward, sp);    \
+    } while (0)
+#define ADC_LEAN(N)                                                                                                         \
+    do {                                                                                                                    \
+        if (vertical) { if (disp_wta) ADC_LEAN_K(N, 1, true); else ADC_LEAN_K(N, 1, false); }                               \
+        else { if (disp_wta) ADC_LEAN_K(N, 0, true); else ADC_LEAN_K(N, 0, false); }                                        \
     } while (0)
         switch (g.NV) {
             case 1: ADC_LEAN(1); break;
@@ -838,6 +871,7 @@ void launch_scanline_pass(const float *src, float *dst, const Planes &p, const G
             case 4: ADC_LEAN(4); break;
             default: ADC_LEAN(8); break;
         }
+#undef ADC_LEAN_K
 #undef ADC_LEAN
         return;
     }
