@@ -130,7 +130,7 @@ def test_tiny_images(pkg, orc):
 
 
 @pytest.mark.parametrize("seed,W,H,dmin,dmax", [(51, 203, 117, 0, 48), (52, 230, 150, 3, 133), (53, 150, 40, 0, 300),
-                                                 (54, 700, 64, -4, 60), (55, 5, 3, 0, 5)])
+                                                 (54, 700, 64, -4, 60), (55, 5, 3, 0, 5), (57, 1920, 72, 5, 261)])
 def test_cost_fused_first_pass(pkg, orc, synth, seed, W, H, dmin, dmax):
     """Without the debug taps the initial costs are computed inside the first aggregation pass; the final
     scanline volume and the final map (both readable without taps) must still be the oracle's bits."""
