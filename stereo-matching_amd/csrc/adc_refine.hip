@@ -382,16 +382,30 @@ k_interp(const float *__restrict__ disp, const uint8_t *__restrict__ occ, const 
         bool walking = live && (m || o);
         // Branch-free body: every lane loads INTERP_STEPS samples (from its own pixel when the sample is
         // outside the image or the lane has finished), then the flags advance by selects.
+        // the table entries of a batch are read one batch ahead: table read -> sample load is a dependent chain
+        uint32_t onx[INTERP_STEPS];
+        if (INT_TAB) {
+#pragma unroll
+            for (int u = 0; u < INTERP_STEPS; u++) onx[u] = off[min(1 + u, maxlen - 1)];
+        }
         for (int mm = 1; mm < maxlen && __any(walking); mm += INTERP_STEPS) {
             float d[INTERP_STEPS];
             uint32_t q[INTERP_STEPS];
             bool in[INTERP_STEPS];
+            uint32_t ocur[INTERP_STEPS];
+            if (INT_TAB) {
+#pragma unroll
+                for (int u = 0; u < INTERP_STEPS; u++) {
+                    ocur[u] = onx[u];
+                    onx[u] = off[min(mm + INTERP_STEPS + u, maxlen - 1)];
+                }
+            }
 #pragma unroll
             for (int u = 0; u < INTERP_STEPS; u++) {
                 const int mi = min(mm + u, maxlen - 1);
                 int yy, xx;
                 if (INT_TAB) {
-                    const uint32_t o2 = off[mi];
+                    const uint32_t o2 = ocur[u];
                     yy = y + ((int)o2 >> 16);
                     xx = x + (int)(short)(o2 & 0xffffu);
                 } else {
