@@ -414,7 +414,15 @@ k_interp(const float *__restrict__ disp, const uint8_t *__restrict__ occ, const 
                 }
                 in[u] = (mm + u < maxlen) & ((unsigned)yy < (unsigned)H) & ((unsigned)xx < (unsigned)W);
                 q[u] = in[u] ? (uint32_t)yy * (uint32_t)W + (uint32_t)xx : p;
-                d[u] = disp[q[u]];
+            }
+            // lanes whose ray has ended issue no loads: the samples are scattered 4-byte reads, one cache line
+            // per lane, and the address path of the vector cache is what this kernel saturates
+            if (walking) {
+#pragma unroll
+                for (int u = 0; u < INTERP_STEPS; u++) d[u] = disp[q[u]];
+            } else {
+#pragma unroll
+                for (int u = 0; u < INTERP_STEPS; u++) d[u] = ADC_INF;
             }
 #pragma unroll
             for (int u = 0; u < INTERP_STEPS; u++) {
