@@ -7,9 +7,10 @@ namespace adc {
 
 __device__ __forceinline__ int color_dist(uint32_t p, uint32_t q) {
     // max over the three channels of |p - q| (ColorDist, ADC/cross_aggregator.h:73-75)
-    const int d0 = abs((int)(p & 0xff) - (int)(q & 0xff));
-    const int d1 = abs((int)((p >> 8) & 0xff) - (int)((q >> 8) & 0xff));
-    const int d2 = abs((int)((p >> 16) & 0xff) - (int)((q >> 16) & 0xff));
+    // one channel masked in place on both sides: v_sad_u8 (sum of absolute byte differences) is that channel's |p - q|
+    const int d0 = (int)__builtin_amdgcn_sad_u8(p & 0xffu, q & 0xffu, 0u);
+    const int d1 = (int)__builtin_amdgcn_sad_u8(p & 0xff00u, q & 0xff00u, 0u);
+    const int d2 = (int)__builtin_amdgcn_sad_u8(p & 0xff0000u, q & 0xff0000u, 0u);
     return max(d0, max(d1, d2));
 }
 
@@ -125,7 +126,19 @@ __global__ void __launch_bounds__(256) k_arms(const uint32_t *__restrict__ pix, 
     const size_t i0 = in ? (size_t)y * W + x : 0;
     const uint32_t p0 = pix[i0];
     const int dx[4] = {-1, 1, 0, 0}, dy[4] = {0, 0, -1, 1};   // left, right, top, bottom (ADC/cross_aggregator.h:13)
-    uint32_t arm[4] = {0, 0, 0, 0}, last[4] = {p0, p0, p0, p0};
+    // A pixel is kept as its three channels masked in place: |difference| of one channel is then one v_sad_u8
+    // (sum of absolute byte differences, the other bytes being zero), the colour distance three of them and a max3.
+    struct Ch { uint32_t b, g, r; };
+    auto split = [](uint32_t v) { return Ch{v & 0xffu, v & 0xff00u, v & 0xff0000u}; };
+    auto dist = [](const Ch &a, const Ch &c) {
+        const int d0 = (int)__builtin_amdgcn_sad_u8(a.b, c.b, 0u);
+        const int d1 = (int)__builtin_amdgcn_sad_u8(a.g, c.g, 0u);
+        const int d2 = (int)__builtin_amdgcn_sad_u8(a.r, c.r, 0u);
+        return max(d0, max(d1, d2));
+    };
+    const Ch c0 = split(p0);
+    uint32_t arm[4] = {0, 0, 0, 0};
+    Ch last[4] = {c0, c0, c0, c0};
     bool alive[4] = {in, in, in, in};
     for (int n = 0; n < cap && __any(alive[0] | alive[1] | alive[2] | alive[3]); n++) {
         uint32_t p[4];
@@ -138,12 +151,13 @@ __global__ void __launch_bounds__(256) k_arms(const uint32_t *__restrict__ pix, 
         }
 #pragma unroll
         for (int d = 0; d < 4; d++) {
-            const int d1 = color_dist(p[d], p0);
+            const Ch c = split(p[d]);
+            const int d1 = dist(c, c0);
             bool go = inside[d] & (d1 < t1);
-            go &= (n == 0) | (color_dist(p[d], last[d]) < t1);
+            go &= (n == 0) | (dist(c, last[d]) < t1);
             go &= (n + 1 <= L2) | (d1 < t2);
             arm[d] += go;
-            last[d] = p[d];
+            last[d] = c;
             alive[d] = go;
         }
     }
@@ -166,14 +180,23 @@ __global__ void __launch_bounds__(256) k_sup_counts(const uint32_t *__restrict__
     const size_t i = (size_t)y * W + x;
     const uint32_t a = arms[i];
     const int l = a & 0xff, r = (a >> 8) & 0xff, t = (a >> 16) & 0xff, b = a >> 24;
+    // four rows / columns per trip, so that four loads are in flight per lane (the sums are integers: any order)
     int ch = 0, cv = 0;
-    for (int dy = -t; dy <= b; dy++) {
-        const uint32_t q = arms[i + (ptrdiff_t)dy * W];
-        ch += (int)(q & 0xff) + (int)((q >> 8) & 0xff) + 1;
+    for (int dy = -t; dy <= b; dy += 4) {
+        uint32_t q[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) q[u] = arms[i + (ptrdiff_t)min(dy + u, b) * W];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (dy + u <= b) ch += (int)(q[u] & 0xff) + (int)((q[u] >> 8) & 0xff) + 1;
     }
-    for (int dx = -l; dx <= r; dx++) {
-        const uint32_t q = arms[i + dx];
-        cv += (int)((q >> 16) & 0xff) + (int)(q >> 24) + 1;
+    for (int dx = -l; dx <= r; dx += 4) {
+        uint32_t q[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) q[u] = arms[i + min(dx + u, r)];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (dx + u <= r) cv += (int)((q[u] >> 16) & 0xff) + (int)(q[u] >> 24) + 1;
     }
     cnt_h[i] = (uint16_t)ch;
     cnt_v[i] = (uint16_t)cv;
