@@ -45,6 +45,11 @@ template <> struct VecT<2> { typedef float T __attribute__((ext_vector_type(2)))
 __device__ __forceinline__ void ring_fill(const float *gsrc, float *lds_dst) {
     __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void *)lds_dst, 4, 0, 0);
 }
+// The second 64 floats of a 128-float slot: the instruction offset moves the global and the LDS address alike,
+// so both halves use one address pair and one M0 value.
+__device__ __forceinline__ void ring_fill_hi(const float *gsrc, float *lds_dst) {
+    __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void *)lds_dst, 4, 256, 0);
+}
 
 // One ring read = one ds_read_b32 / ds_read_b64. The access is volatile so that the compiler does not
 // pair two of them into ds_read2(st64)_b64: on gfx950 the paired form runs at half the LDS rate
@@ -300,7 +305,9 @@ struct CostSrc {
     const float *lut_ad, *lut_cen;
     int dmin, D;
 };
-template <int VEC, bool DIV, bool COST>
+// FULLD: Dp is a multiple of the chunk (64*VEC disparities), so every lane of every chunk is live and the
+// fills / stores need no lane predicate (each predicate costs an execution-mask save, a branch and a restore).
+template <int VEC, bool DIV, bool COST, bool FULLD>
 __global__ void __launch_bounds__(AGG_WAVES * 64)
 k_agg_pair(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ arms,
            const uint32_t *__restrict__ cnt, int W, int H, int Dp, int vertical, int seglen, int cap, int R,
@@ -325,9 +332,9 @@ k_agg_pair(const float *__restrict__ src, float *__restrict__ dst, const uint32_
     const int sh_neg = vertical ? 16 : 0, sh_pos = vertical ? 24 : 8;
     bool fok[VEC];
 #pragma unroll
-    for (int h = 0; h < VEC; h++) fok[h] = kc + h * 64 + lane < Dp;
+    for (int h = 0; h < VEC; h++) fok[h] = FULLD || kc + h * 64 + lane < Dp;
     const float *fsrc = src + lbase + lane;
-    const bool kok = kc + lane * VEC < Dp;
+    const bool kok = FULLD || kc + lane * VEC < Dp;
     const float *rl = ring + lane * VEC;
 
     // COST: right-row entries any (position, disparity) pair of this segment and chunk can touch, i.e.
@@ -420,9 +427,14 @@ k_agg_pair(const float *__restrict__ src, float *__restrict__ dst, const uint32_
                 if (COST) {
                     cost_fill(n0 + 2 * wave + j, q);
                 } else {
+                    if constexpr (FULLD && VEC == 2) {
+                        ring_fill(fill_p + (ptrdiff_t)j * mstride, ring + q * SLOT);
+                        ring_fill_hi(fill_p + (ptrdiff_t)j * mstride, ring + q * SLOT);
+                    } else {
 #pragma unroll
-                    for (int h = 0; h < VEC; h++)
-                        if (fok[h]) ring_fill(fill_p + (ptrdiff_t)j * mstride + h * 64, ring + q * SLOT + h * 64);
+                        for (int h = 0; h < VEC; h++)
+                            if (fok[h]) ring_fill(fill_p + (ptrdiff_t)j * mstride + h * 64, ring + q * SLOT + h * 64);
+                    }
                 }
             }
         }
@@ -573,20 +585,29 @@ static void launch_pair(const float *src, float *dst, const uint32_t *arms, cons
     }
     nseg = (LEN + seglen - 1) / seglen;
     dim3 grid(chunks, lines, nseg), block(AGG_WAVES * 64);
+#ifdef AGG_NO_FULLD
+    const bool fulld = false;
+#else
+    const bool fulld = g.Dp % SLOT == 0;
+#endif
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_agg_pair<VEC, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_agg_pair<VEC, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_agg_pair<VEC, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+#define ADC_PAIR_ATTR(D_, C_, F_) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_agg_pair<VEC, D_, C_, F_>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)
+        ADC_PAIR_ATTR(true, false, true); ADC_PAIR_ATTR(false, false, true); ADC_PAIR_ATTR(false, true, true);
+        ADC_PAIR_ATTR(true, false, false); ADC_PAIR_ATTR(false, false, false); ADC_PAIR_ATTR(false, true, false);
+#undef ADC_PAIR_ATTR
         attr_set = true;
     }
     const CostSrc none = {};
-    if (cost)
-        k_agg_pair<VEC, false, true><<<grid, block, lds, s>>>(src, dst, arms, cnt, g.W, g.H, g.Dp, vertical, seglen, max_arm, R, *cost);
-    else if (cnt)
-        k_agg_pair<VEC, true, false><<<grid, block, lds, s>>>(src, dst, arms, cnt, g.W, g.H, g.Dp, vertical, seglen, max_arm, R, none);
-    else
-        k_agg_pair<VEC, false, false><<<grid, block, lds, s>>>(src, dst, arms, cnt, g.W, g.H, g.Dp, vertical, seglen, max_arm, R, none);
+#define ADC_PAIR_GO(D_, C_, CS_)                                                                                              \
+    do {                                                                                                                      \
+        if (fulld) k_agg_pair<VEC, D_, C_, true><<<grid, block, lds, s>>>(src, dst, arms, cnt, g.W, g.H, g.Dp, vertical, seglen, max_arm, R, CS_); \
+        else k_agg_pair<VEC, D_, C_, false><<<grid, block, lds, s>>>(src, dst, arms, cnt, g.W, g.H, g.Dp, vertical, seglen, max_arm, R, CS_);      \
+    } while (0)
+    if (cost) ADC_PAIR_GO(false, true, *cost);
+    else if (cnt) ADC_PAIR_GO(true, false, none);
+    else ADC_PAIR_GO(false, false, none);
+#undef ADC_PAIR_GO
 }
 
 static bool pair_kernel_ok(const Geom &g, int max_arm) {
