@@ -178,30 +178,42 @@ k_vote(const float *__restrict__ disp, const short *__restrict__ binmap, const u
                 // vmcnt(0), which also waits for the row loads just issued and serialises them
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(arow));
                 for (int t0 = 0; t0 < nr; t0 += VOTE_ROWS) {
-                    int ba[VOTE_ROWS], bb[VOTE_ROWS];   // 32-bit: 16-bit values get packed in pairs, which serialises the loads
+                    // a lane reads two neighbouring pixels of a row with one (possibly unaligned) 4-byte load: the
+                    // vector cache's address path is what limits this loop, and half as many lanes issue a load
+                    uint32_t bw[VOTE_ROWS], bw2[VOTE_ROWS];
+                    int sp[VOTE_ROWS];
                     bool any_b = false;
 #pragma unroll
                     for (int u = 0; u < VOTE_ROWS; u++) {
-                        ba[u] = -1;
-                        bb[u] = -1;
+                        bw[u] = 0xffffffffu;
+                        bw2[u] = 0xffffffffu;
+                        sp[u] = -1;
                         if (t0 + u < nr) {                                   // uniform
                             const uint32_t a2 = __builtin_amdgcn_readlane(arow, t0 + u);
                             const int l2 = a2 & 0xff, r2 = (a2 >> 8) & 0xff;
                             const short *row = binmap + qrow + (size_t)(t0 + u) * W - l2;
-                            if (lane <= l2 + r2) ba[u] = row[lane];
-                            if (l2 + r2 >= 64) {                             // uniform, spans longer than a wave
+                            const int span = l2 + r2;                        // pixels 0 .. span
+                            sp[u] = span;
+                            if (2 * lane <= span) bw[u] = *reinterpret_cast<const uint32_t *>(row + 2 * lane);
+                            if (span >= 128) {                               // uniform, spans longer than 128 pixels
                                 any_b = true;
-                                if (lane + 64 <= l2 + r2) bb[u] = row[lane + 64];
+                                if (2 * lane + 128 <= span) bw2[u] = *reinterpret_cast<const uint32_t *>(row + 2 * lane + 128);
                             }
                         }
                     }
 #pragma unroll
-                    for (int u = 0; u < VOTE_ROWS; u++)
-                        if (ba[u] >= 0) atomicAdd(&hist[hcopy + ba[u]], 1);
+                    for (int u = 0; u < VOTE_ROWS; u++) {
+                        const int lo = (short)(bw[u] & 0xffffu), hi = (short)(bw[u] >> 16);
+                        if (2 * lane <= sp[u] && lo >= 0) atomicAdd(&hist[hcopy + lo], 1);
+                        if (2 * lane + 1 <= sp[u] && hi >= 0) atomicAdd(&hist[hcopy + hi], 1);
+                    }
                     if (any_b) {
 #pragma unroll
-                        for (int u = 0; u < VOTE_ROWS; u++)
-                            if (bb[u] >= 0) atomicAdd(&hist[hcopy + bb[u]], 1);
+                        for (int u = 0; u < VOTE_ROWS; u++) {
+                            const int lo = (short)(bw2[u] & 0xffffu), hi = (short)(bw2[u] >> 16);
+                            if (2 * lane + 128 <= sp[u] && lo >= 0) atomicAdd(&hist[hcopy + lo], 1);
+                            if (2 * lane + 129 <= sp[u] && hi >= 0) atomicAdd(&hist[hcopy + hi], 1);
+                        }
                     }
                 }
             }
