@@ -105,6 +105,16 @@ typedef enum adc_stage_id {
     ADC_STAGE_COUNT_
 } adc_stage_id;
 
+/* The volume kernels of one match, in launch order, as timed one by one by adc_kernel_times (HIP events on
+ * the launch stream around every launch). The reference times whole stages only (ADC/ADCensusStereo.cu:76-143). */
+typedef enum adc_kernel_id {
+    ADC_KERNEL_COST = 0,     /* initial cost volume as a kernel of its own (0 ms when it is fused into AGGR0) */
+    ADC_KERNEL_AGGR0 = 1,    /* aggregation passes 0..7: ids 1..8 (H,V | V,H | H,V | V,H; odd passes divide)   */
+    ADC_KERNEL_SCAN0 = 9,    /* scanline passes 0..3: ids 9..12 (left-right, right-left, up-down, down-up)     */
+    ADC_KERNEL_WTA_RIGHT = 13,
+    ADC_KERNEL_COUNT_ = 14
+} adc_kernel_id;
+
 /* Fills *opt with ADCensusOption's defaults (ADC/adcensus_types.h:86-93). */
 void adc_default_option(adc_option *opt);
 
@@ -145,9 +155,20 @@ int adc_set_profiling(adc_handle *h, int enable);
  * Replaces the reference's printf timing (ADC/ADCensusStereo.cu:76-143). */
 int adc_stage_times(adc_handle *h, float *ms, int n);
 
+/* Copies up to n (<= ADC_KERNEL_COUNT_) per-launch device times in ms of the last profiled match into ms[],
+ * indexed by adc_kernel_id. For per-kernel roofline accounting. */
+int adc_kernel_times(adc_handle *h, float *ms, int n);
+
 /* Number of launches of the dominant aggregation kernel in one match and the device time of the
- * last profiled match spent in them, for roofline accounting. */
+ * last profiled match spent in them (the sum of their adc_kernel_times entries). */
 int adc_aggr_kernel_stats(adc_handle *h, int *launches, float *total_ms);
+
+/* What the last profiled adc_match spent around the pipeline, in ms: ms[0] host copy of the two images into
+ * pinned staging (0 when the caller's images are pinned host memory: they are then the DMA source), ms[1]
+ * upload of the two images (device time), ms[2] download of the map (device time), ms[3] host copy of the map
+ * out of pinned staging (0 for a pinned destination). The reference's Match does the same transfers around
+ * every stage (ADC/cost_computor.cu:91-120,209-269). */
+int adc_transfer_times(adc_handle *h, float *ms, int n);
 
 /* Size in bytes of a tap in the reference layout (0 if unknown id or not initialised). */
 size_t adc_buffer_bytes(adc_handle *h, adc_buffer_id id);
@@ -156,9 +177,12 @@ size_t adc_buffer_bytes(adc_handle *h, adc_buffer_id id);
  * reference's get_*_ptr() accessors (ADC/cost_computor.cu:287-295, ADC/cost_aggregator.cu:115-128). */
 int adc_get_buffer(adc_handle *h, adc_buffer_id id, void *dst, size_t bytes);
 
-/* Frame-sharded batch: n_pairs independent stereo pairs (host pointers), pair i on
- * devices[i % n_devices], one handle and one host thread per device, no inter-GPU traffic.
- * The reference processes its dataset list one pair after another on one GPU
+/* Frame-sharded batch: n_pairs independent stereo pairs (host pointers) over n_devices GPUs, one host
+ * thread per device, no inter-GPU traffic. The devices draw pair indices from one shared counter, so a
+ * device that finishes early takes the next pair. handles == NULL: a handle per device is created and
+ * initialised for the call and destroyed at its end; otherwise handles[i] is the caller's handle on
+ * devices[i], already initialised with this width, height and option, and is reused (nothing is allocated
+ * from the second call on). The reference processes its dataset list one pair after another on one GPU
  * (ADC/main.cpp:62-255); this is that loop spread over the GPUs of a node. */
 typedef struct adc_batch_desc {
     int32_t width, height;
@@ -169,6 +193,7 @@ typedef struct adc_batch_desc {
     float *const *disp_left;          /* n_pairs host pointers */
     int32_t n_devices;
     const int32_t *devices;           /* HIP device ordinals */
+    adc_handle *const *handles;       /* NULL, or n_devices initialised handles (see above) */
 } adc_batch_desc;
 int adc_match_batch(const adc_batch_desc *desc);
 

@@ -29,6 +29,15 @@ int orc_num_threads(void) {
 #endif
 }
 
+/* Thread count of the calls that follow (the CPU baseline is timed at all cores and at one). */
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n >= 1) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* Defaults of ADCensusOption(), ADC/adcensus_types.h:86-93 with ADC/config.h:12-13,26-29. */
 void orc_default_option(orc_option *o) {
     memset(o, 0, sizeof(*o));

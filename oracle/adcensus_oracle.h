@@ -112,6 +112,7 @@ double orc_bad_fraction(const float *disp, const uint8_t *gt, int W, int H, floa
                         float delta, double *rms);
 
 int orc_num_threads(void);
+void orc_set_num_threads(int n);
 
 /* Literal-defect switches: reproduce, one by one, deterministic defects of the shipped CUDA code that
  * the canonical semantics above repair. They exist to measure how far canonical output is from what

@@ -132,6 +132,10 @@ def num_threads():
     return lib().orc_num_threads()
 
 
+def set_num_threads(n):
+    lib().orc_set_num_threads(C.c_int(int(n)))
+
+
 def match(left_bgr, right_bgr, opt=None, want=()):
     """Run the whole pipeline. Returns (disp f32[H][W], {tap name: array}).
 

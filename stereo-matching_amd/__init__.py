@@ -5,5 +5,6 @@ The directory name carries a hyphen, so import it with
 (with the repository root on sys.path).
 """
 from . import adcensus  # noqa: F401
-from .adcensus import (ADCensusOption, ADCensusStereo, BUFFERS, EXPORTS, HARNESS_EXPORTS, LIB_PATH, STAGES,  # noqa: F401
-                       lib, match_batch)
+from .adcensus import (ADC_ERR_ARG, ADC_ERR_HIP, ADC_ERR_NOMEM, ADC_ERR_NOT_INIT, ADC_ERR_UNSUPPORTED, ADC_OK,  # noqa: F401
+                       ADCensusOption, ADCensusStereo, BUFFERS, EXPORTS, HARNESS_EXPORTS, KERNELS, LIB_PATH, STAGES, lib,
+                       match_batch)

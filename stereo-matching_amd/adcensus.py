@@ -50,6 +50,7 @@ class BatchDesc(C.Structure):
         ("disp_left", C.POINTER(C.c_void_p)),
         ("n_devices", C.c_int32),
         ("devices", C.POINTER(C.c_int32)),
+        ("handles", C.POINTER(C.c_void_p)),
     ]
 
 
@@ -73,12 +74,15 @@ BUFFERS = {
     "disp_final": (22, np.float32, "px"),
 }
 STAGES = ["pre", "cost", "aggr", "scan", "wta", "refine", "total"]
+# adc_kernel_id: the volume kernels of one match in launch order
+KERNELS = ["cost"] + ["aggr%d" % i for i in range(8)] + ["scan%d" % i for i in range(4)] + ["wta_right"]
 
 # every symbol include/adcensus.h declares
 EXPORTS = [
     "adc_default_option", "adc_create", "adc_destroy", "adc_initialize", "adc_reset", "adc_match",
     "adc_match_device", "adc_synchronize", "adc_set_debug_taps", "adc_set_profiling", "adc_stage_times",
     "adc_aggr_kernel_stats", "adc_buffer_bytes", "adc_get_buffer", "adc_match_batch", "adc_last_error",
+    "adc_kernel_times", "adc_transfer_times",
 ]
 # ... and include/adcensus_harness.h
 HARNESS_EXPORTS = ["adc_png_read", "adc_image_free", "adc_png_write_gray", "adc_disparity_to_u8", "adc_eval_0103",
@@ -111,6 +115,8 @@ def lib():
         L.adc_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.adc_stage_times.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.adc_aggr_kernel_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.adc_kernel_times.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.adc_transfer_times.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.adc_buffer_bytes.restype = C.c_size_t
         L.adc_buffer_bytes.argtypes = [C.c_void_p, C.c_int]
         L.adc_get_buffer.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
@@ -174,9 +180,15 @@ class ADCensusStereo:
 
     def Match(self, img_left, img_right, disp_left):
         """img_left/img_right: BGR u8[H][W][3] numpy arrays (or None); disp_left: f32[H][W] output."""
-        pl = self._host_ptr(img_left, np.uint8, 3)
-        pr = self._host_ptr(img_right, np.uint8, 3)
-        pd = self._host_ptr(disp_left, np.float32, 1)
+        try:
+            pl = self._host_ptr(img_left, np.uint8, 3)
+            pr = self._host_ptr(img_right, np.uint8, 3)
+            pd = self._host_ptr(disp_left, np.float32, 1)
+        except ValueError:
+            # the library copies width*height*3 bytes from each image and width*height floats to the map,
+            # whatever the arrays hold: a wrong shape is refused here like the reference's `return false`
+            self.status = ADC_ERR_ARG
+            return False
         self.status = lib().adc_match(self._h, pl, pr, pd)
         return self.status == ADC_OK
 
@@ -219,6 +231,22 @@ class ADCensusStereo:
             raise RuntimeError("adc_aggr_kernel_stats failed: %s" % self.last_error())
         return n.value, t.value
 
+    def kernel_times(self):
+        """Per-launch device times (ms) of the last profiled match, by KERNELS name."""
+        ms = (C.c_float * len(KERNELS))()
+        rc = lib().adc_kernel_times(self._h, ms, len(KERNELS))
+        if rc != ADC_OK:
+            raise RuntimeError("adc_kernel_times failed: %s" % self.last_error())
+        return dict(zip(KERNELS, [float(v) for v in ms]))
+
+    def transfer_times(self):
+        """Of the last profiled Match: host copy in, upload, download, host copy out (ms)."""
+        ms = (C.c_float * 4)()
+        rc = lib().adc_transfer_times(self._h, ms, 4)
+        if rc != ADC_OK:
+            raise RuntimeError("adc_transfer_times failed: %s" % self.last_error())
+        return dict(zip(["host_in", "h2d", "d2h", "host_out"], [float(v) for v in ms]))
+
     def get_buffer(self, name):
         bid, dt, kind = BUFFERS[name]
         D = self.option.max_disparity - self.option.min_disparity
@@ -236,21 +264,36 @@ class ADCensusStereo:
         return lib().adc_last_error(self._h).decode()
 
     def _host_ptr(self, a, dtype, ch):
+        """Address of a contiguous array of the initialised frame's shape ((H, W, 3) images, (H, W) map)."""
         if a is None:
             return None
-        assert isinstance(a, np.ndarray) and a.dtype == dtype and a.flags["C_CONTIGUOUS"], "contiguous %s array expected" % dtype
+        want = (self.height, self.width, 3) if ch == 3 else (self.height, self.width)
+        if not (isinstance(a, np.ndarray) and a.dtype == dtype and a.flags["C_CONTIGUOUS"]):
+            raise ValueError("contiguous %s array expected" % np.dtype(dtype).name)
+        if self.width and a.shape != want:
+            raise ValueError("array of shape %s expected, got %s" % (want, a.shape))
         return a.ctypes.data
 
 
-def match_batch(lefts, rights, option, devices):
-    """adc_match_batch: pair i runs on devices[i % len(devices)]. Returns the list of disparity maps."""
+def match_batch(lefts, rights, option, devices, handles=None, out=None):
+    """adc_match_batch: the pairs are spread over `devices` (each device takes the next unmatched pair when it
+    is free). handles: ADCensusStereo objects, one per device, already initialised for this size and option,
+    reused instead of a create/initialise/destroy per call. out: preallocated f32[H][W] arrays to fill.
+    Returns the list of disparity maps."""
     n = len(lefts)
     if n == 0:
         return []
+    if len(rights) != n:
+        raise ValueError("as many right images as left images expected")
     H, W = lefts[0].shape[:2]
+    for a in list(lefts) + list(rights):
+        if a.shape != (H, W, 3):
+            raise ValueError("every image must have shape %s, got %s" % ((H, W, 3), a.shape))
     lefts = [np.ascontiguousarray(a, np.uint8) for a in lefts]
     rights = [np.ascontiguousarray(a, np.uint8) for a in rights]
-    disps = [np.empty((H, W), np.float32) for _ in range(n)]
+    disps = out if out is not None else [np.empty((H, W), np.float32) for _ in range(n)]
+    if len(disps) != n or any(a.shape != (H, W) or a.dtype != np.float32 or not a.flags["C_CONTIGUOUS"] for a in disps):
+        raise ValueError("out must hold one contiguous f32 (H, W) array per pair")
     d = BatchDesc()
     d.width, d.height, d.option, d.n_pairs = W, H, option, n
     d.left_bgr = (C.c_void_p * n)(*[a.ctypes.data for a in lefts])
@@ -258,6 +301,10 @@ def match_batch(lefts, rights, option, devices):
     d.disp_left = (C.c_void_p * n)(*[a.ctypes.data for a in disps])
     d.n_devices = len(devices)
     d.devices = (C.c_int32 * len(devices))(*devices)
+    if handles is not None:
+        if len(handles) != len(devices):
+            raise ValueError("one handle per device expected")
+        d.handles = (C.c_void_p * len(handles))(*[h._h for h in handles])
     rc = lib().adc_match_batch(C.byref(d))
     if rc != ADC_OK:
         raise RuntimeError("adc_match_batch failed (%d): %s" % (rc, lib().adc_last_error(None).decode()))

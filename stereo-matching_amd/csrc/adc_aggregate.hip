@@ -549,12 +549,6 @@ static void launch_ring(const float *src, float *dst, const uint32_t *arms, cons
     if (seglen < 128) seglen = 128;
     nseg = (LEN + seglen - 1) / seglen;
     dim3 grid(chunks, lines, nseg), block(AGG_WAVES * 64);
-    static bool attr_set = false;   // per template instance: allow the full 64 KB of dynamic LDS
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_agg_ring<VEC, true, DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_agg_ring<VEC, false, DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        attr_set = true;
-    }
     if (cnt)
         k_agg_ring<VEC, true, DEPTH><<<grid, block, lds, s>>>(src, dst, arms, cnt, g.W, g.H, g.Dp, vertical, seglen, max_arm, R - 1);
     else
@@ -590,14 +584,6 @@ static void launch_pair(const float *src, float *dst, const uint32_t *arms, cons
 #else
     const bool fulld = g.Dp % SLOT == 0;
 #endif
-    static bool attr_set = false;
-    if (!attr_set) {
-#define ADC_PAIR_ATTR(D_, C_, F_) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_agg_pair<VEC, D_, C_, F_>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)
-        ADC_PAIR_ATTR(true, false, true); ADC_PAIR_ATTR(false, false, true); ADC_PAIR_ATTR(false, true, true);
-        ADC_PAIR_ATTR(true, false, false); ADC_PAIR_ATTR(false, false, false); ADC_PAIR_ATTR(false, true, false);
-#undef ADC_PAIR_ATTR
-        attr_set = true;
-    }
     const CostSrc none = {};
 #define ADC_PAIR_GO(D_, C_, CS_)                                                                                              \
     do {                                                                                                                      \
@@ -610,10 +596,39 @@ static void launch_pair(const float *src, float *dst, const uint32_t *arms, cons
 #undef ADC_PAIR_GO
 }
 
+// The dynamic-LDS opt-in of every instantiation a launcher above can pick (the ring kernels use up to 64 KB,
+// the pair kernel up to 80 KB), on the current device. A kernel attribute belongs to the device it was set
+// on, so every handle does this for its own device when it is initialised; nothing is cached per process.
+template <int VEC>
+static hipError_t setup_vec() {
+    hipError_t e = hipSuccess;
+    auto set = [&e](const void *f, int bytes) {
+        if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    };
+#define ADC_RING_ATTR(D_) \
+    set(reinterpret_cast<const void *>(&k_agg_ring<VEC, true, D_>), 64 * 1024); \
+    set(reinterpret_cast<const void *>(&k_agg_ring<VEC, false, D_>), 64 * 1024)
+    ADC_RING_ATTR(2); ADC_RING_ATTR(4); ADC_RING_ATTR(6);
+#undef ADC_RING_ATTR
+#define ADC_PAIR_ATTR(D_, C_, F_) set(reinterpret_cast<const void *>(&k_agg_pair<VEC, D_, C_, F_>), 80 * 1024)
+    ADC_PAIR_ATTR(true, false, true); ADC_PAIR_ATTR(false, false, true); ADC_PAIR_ATTR(false, true, true);
+    ADC_PAIR_ATTR(true, false, false); ADC_PAIR_ATTR(false, false, false); ADC_PAIR_ATTR(false, true, false);
+#undef ADC_PAIR_ATTR
+    return e;
+}
+hipError_t aggregate_setup_device() {
+    const hipError_t e = setup_vec<1>();
+    return e != hipSuccess ? e : setup_vec<2>();
+}
+
 static bool pair_kernel_ok(const Geom &g, int max_arm) {
     static const int pair_env = std::getenv("ADC_AGG_PAIR") ? std::atoi(std::getenv("ADC_AGG_PAIR")) : 1;
     const int vec = (g.Dp >= 128 && g.Dp % 2 == 0) ? 2 : 1;
-    return pair_env && (long long)g.W * g.Dp * (PAIR_B + 2) < (1ll << 31) &&
+    // div_by_count needs a count in [1, 2^14]: the 16-bit support counts (wrap-around, as the reference's
+    // vec_sup_count_) stay below 2^14 while (2*cap+1)^2 does, i.e. for arm caps up to 63; longer arms take the
+    // ring / direct kernels, whose plain IEEE division also covers a count that wrapped to 0.
+    return pair_env && (2 * max_arm + 1) * (2 * max_arm + 1) <= (1 << 14) &&
+           (long long)g.W * g.Dp * (PAIR_B + 2) < (1ll << 31) &&
            (size_t)(2 * max_arm + 2 * PAIR_B) * 64 * vec * 4 <= 80 * 1024;
 }
 

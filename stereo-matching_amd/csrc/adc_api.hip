@@ -5,9 +5,12 @@
 #include "adc_common.h"
 #include "../../include/adcensus.h"
 
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -17,6 +20,7 @@ using namespace adc;
 namespace {
 thread_local std::string g_thread_error;
 enum { N_AGG_PASSES = 8, N_EVENTS = ADC_STAGE_COUNT_ };  // stage boundaries: PRE|COST|AGGR|SCAN|WTA|REFINE|end
+enum { N_KEV = ADC_KERNEL_COUNT_ + 1 };                  // kernel k runs between kernel events k and k + 1
 }
 
 struct adc_handle {
@@ -33,6 +37,14 @@ struct adc_handle {
     std::vector<void *> dev_allocs;
     std::vector<void *> host_allocs;
     std::vector<hipEvent_t> events;
+    std::vector<hipEvent_t> kevents;   // around every volume kernel (profiling only)
+    hipEvent_t xfer_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // upload start/end, download start/end of adc_match
+    bool have_xfer = false;
+    float host_ms[2] = {0, 0};         // adc_match: staging copies in / out on the host (0 for pinned callers)
+    // arena mode: every device buffer is carved from [arena, arena + arena_size) instead of hipMalloc; no stream,
+    // event or pinned host buffer is created (the caller's stream is used, profiling and adc_match are unavailable)
+    unsigned char *arena = nullptr;
+    size_t arena_size = 0, arena_used = 0;
 
     // images
     uint8_t *d_bgr_l = nullptr, *d_bgr_r = nullptr;
@@ -89,6 +101,17 @@ namespace {
 template <typename T>
 int dev_alloc(adc_handle *h, T **p, size_t count) {
     void *q = nullptr;
+    if (h->arena) {
+        const size_t bytes = (count * sizeof(T) + 256 + 255) & ~(size_t)255;   // same slack as below, 256-byte aligned
+        if (bytes > h->arena_size - h->arena_used) {
+            h->arena_used = h->arena_size + 1;       // remember the overflow; the caller reports the size needed
+            h->err = "frame does not fit the static scratch";
+            return ADC_ERR_UNSUPPORTED;
+        }
+        *p = reinterpret_cast<T *>(h->arena + h->arena_used);
+        h->arena_used += bytes;
+        return ADC_OK;
+    }
     hipError_t e = hipMalloc(&q, count * sizeof(T) + 256);
     if (e != hipSuccess) {
         h->err = std::string("hipMalloc: ") + hipGetErrorString(e);
@@ -116,9 +139,13 @@ void release(adc_handle *h) {
     for (void *p : h->dev_allocs) hipFree(p);
     for (void *p : h->host_allocs) hipHostFree(p);
     for (hipEvent_t e : h->events) hipEventDestroy(e);
+    for (hipEvent_t e : h->kevents) hipEventDestroy(e);
+    for (hipEvent_t &e : h->xfer_ev) { if (e) hipEventDestroy(e); e = nullptr; }
     h->dev_allocs.clear();
     h->host_allocs.clear();
     h->events.clear();
+    h->kevents.clear();
+    h->have_xfer = false;
     if (h->stream) { hipStreamDestroy(h->stream); h->stream = nullptr; }
     h->snap_init = h->snap_aggr = nullptr;
     h->pipe_d_o[0] = h->pipe_d_o[1] = nullptr;
@@ -141,7 +168,9 @@ int alloc_debug(adc_handle *h) {
     return ADC_OK;
 }
 
-int do_initialize(adc_handle *h, int32_t W, int32_t H, const adc_option *opt) {
+// s0: the stream the set-up work (memsets, table uploads) runs on; the handle's own stream unless the handle
+// lives in the static scratch, where it is the caller's.
+int do_initialize(adc_handle *h, int32_t W, int32_t H, const adc_option *opt, hipStream_t s0 = nullptr) {
     if (!opt) return h->fail(ADC_ERR_ARG, "adc_initialize: option is null");
     // ADCensusStereo::Initialize rejects w,h <= 0 and an empty disparity range (ADC/ADCensusStereo.cu:26-35)
     if (W <= 0 || H <= 0) return h->fail(ADC_ERR_ARG, "adc_initialize: width and height must be positive");
@@ -155,19 +184,31 @@ int do_initialize(adc_handle *h, int32_t W, int32_t H, const adc_option *opt) {
     if (H > 65535 || W > 65535)
         return h->fail(ADC_ERR_UNSUPPORTED, "adc_initialize: image side larger than 65535");
 
+    const bool in_arena = h->arena != nullptr;
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    if (!in_arena) {
+        HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        s0 = h->stream;
+    }
+    // kernel attributes belong to the device they were set on: every handle opts its own device in
+    HIPCHK(h, aggregate_setup_device());
+    HIPCHK(h, scanline_setup_device());
     h->opt = *opt;
     Geom &g = h->g;
     g.W = W; g.H = H; g.dmin = opt->min_disparity; g.dmax = opt->max_disparity; g.D = (int)D64;
     g.NV = 1;
     while (64 * g.NV < g.D) g.NV *= 2;
     g.Dp = ((g.D + g.NV - 1) / g.NV) * g.NV;
+    {
+        int cus = 0;
+        HIPCHK(h, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+        g.simds = 4 * cus;
+    }
 
     const size_t npx = (size_t)W * H, nvol = npx * g.Dp;
     int rc;
 #define A(p, n) if ((rc = dev_alloc(h, &(p), (n)))) return rc
-    A(h->d_bgr_l, npx * 3); A(h->d_bgr_r, npx * 3);
+    if (!in_arena) { A(h->d_bgr_l, npx * 3); A(h->d_bgr_r, npx * 3); }   // adc_match's upload targets
     A(h->pl.pix_l, npx); A(h->pl.pix_r, npx);
     A(h->pl.gray_l, npx); A(h->pl.gray_r, npx);
     A(h->pl.cen_l, npx); A(h->pl.cen_r, npx);
@@ -188,40 +229,42 @@ int do_initialize(adc_handle *h, int32_t W, int32_t H, const adc_option *opt) {
     A(h->newval, 2 * npx);
     A(h->binmap, npx);
     A(h->tile_stamp, (size_t)vote_tiles_w(W) * vote_tiles_h(H));
-    A(h->tap_u64, npx);
+    if (!in_arena) A(h->tap_u64, npx);
+    // ray tables of the 16-direction search: m*sin, m*cos (double) and, when usable, their rounded offsets
+    const int maxlen = std::abs(opt->max_disparity) * 1;  // MaxSearchLengthTimes = 1 (ADC/config.h:24)
+    h->ray_len = maxlen > 1 ? maxlen : 1;
+    const size_t nray = (size_t)16 * h->ray_len;
+    A(h->ray_dy, nray); A(h->ray_dx, nray); A(h->ray_off, nray);
 #undef A
-    if ((rc = host_alloc(h, &h->h_bgr_l, npx * 3))) return rc;
-    if ((rc = host_alloc(h, &h->h_bgr_r, npx * 3))) return rc;
-    if ((rc = host_alloc(h, &h->h_disp, npx))) return rc;
+    if (!in_arena) {
+        if ((rc = host_alloc(h, &h->h_bgr_l, npx * 3))) return rc;
+        if ((rc = host_alloc(h, &h->h_bgr_r, npx * 3))) return rc;
+        if ((rc = host_alloc(h, &h->h_disp, npx))) return rc;
+    }
     // padding columns of the volumes are never produced by the cost kernel; give them a defined value once
-    HIPCHK(h, hipMemsetAsync(h->vol_a, 0, nvol * sizeof(float), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->vol_b, 0, nvol * sizeof(float), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->tile_stamp, 0, (size_t)vote_tiles_w(W) * vote_tiles_h(H) * sizeof(uint32_t), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->vol_a, 0, nvol * sizeof(float), s0));
+    HIPCHK(h, hipMemsetAsync(h->vol_b, 0, nvol * sizeof(float), s0));
+    HIPCHK(h, hipMemsetAsync(h->tile_stamp, 0, (size_t)vote_tiles_w(W) * vote_tiles_h(H) * sizeof(uint32_t), s0));
     h->vote_stamp = 16;
 
     // exp tables of the initial cost (ADC/cost_computor.cu:186,200-203): entry = expf of the float
     // argument, taken as the correctly rounded (float)exp((double)arg).
-    {
-        std::vector<float> ad(768, 0.0f), cen(68, 0.0f);
-        for (int s = 0; s < 766; s++) {
-            const float a = (float)s / 3.0f;
-            const float arg = -a / (float)opt->lambda_ad;
-            ad[s] = (float)std::exp((double)arg);
-        }
-        for (int k = 0; k < 65; k++) {
-            const float arg = -(float)k / (float)opt->lambda_census;
-            cen[k] = (float)std::exp((double)arg);
-        }
-        HIPCHK(h, hipMemcpyAsync(h->lut_ad, ad.data(), 768 * sizeof(float), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->lut_cen, cen.data(), 68 * sizeof(float), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::vector<float> ad(768, 0.0f), cen(68, 0.0f);
+    for (int s = 0; s < 766; s++) {
+        const float a = (float)s / 3.0f;
+        const float arg = -a / (float)opt->lambda_ad;
+        ad[s] = (float)std::exp((double)arg);
     }
-    // ray tables of the 16-direction search (ADC/multistep_refiner.cu:561-583, :642):
-    // ang += PI/16 with PI = 3.1415926f, accumulated in double; entries m*sin(ang), m*cos(ang).
+    for (int k = 0; k < 65; k++) {
+        const float arg = -(float)k / (float)opt->lambda_census;
+        cen[k] = (float)std::exp((double)arg);
+    }
+    HIPCHK(h, hipMemcpyAsync(h->lut_ad, ad.data(), 768 * sizeof(float), hipMemcpyHostToDevice, s0));
+    HIPCHK(h, hipMemcpyAsync(h->lut_cen, cen.data(), 68 * sizeof(float), hipMemcpyHostToDevice, s0));
+    // ray tables (ADC/multistep_refiner.cu:561-583, :642): ang += PI/16 with PI = 3.1415926f, accumulated in
+    // double; entries m*sin(ang), m*cos(ang).
+    std::vector<double> dy(nray, 0.0), dx(nray, 0.0);
     {
-        const int maxlen = std::abs(opt->max_disparity) * 1;  // MaxSearchLengthTimes = 1 (ADC/config.h:24)
-        h->ray_len = maxlen > 1 ? maxlen : 1;
-        std::vector<double> dy((size_t)16 * h->ray_len, 0.0), dx((size_t)16 * h->ray_len, 0.0);
         double ang = 0.0;
         const float step = 3.1415926f / 16;
         for (int s = 0; s < 16; s++) {
@@ -232,32 +275,34 @@ int do_initialize(adc_handle *h, int32_t W, int32_t H, const adc_option *opt) {
             }
             ang += step;
         }
-        if ((rc = dev_alloc(h, &h->ray_dy, dy.size()))) return rc;
-        if ((rc = dev_alloc(h, &h->ray_dx, dx.size()))) return rc;
-        HIPCHK(h, hipMemcpy(h->ray_dy, dy.data(), dy.size() * sizeof(double), hipMemcpyHostToDevice));
-        HIPCHK(h, hipMemcpy(h->ray_dx, dx.data(), dx.size() * sizeof(double), hipMemcpyHostToDevice));
-        // round((double)y + v) == y + round(v) for every integer |y| < 2^16 unless v is within a few ulps
-        // (of 2^17) of a half-integer; with a margin of 1e-6 the integer offsets can replace the doubles.
-        h->ray_off = nullptr;
-        bool int_ok = h->ray_len <= 32000 && !std::getenv("ADC_INTERP_DOUBLE");
-        std::vector<uint32_t> off(dy.size());
-        for (size_t i = 0; int_ok && i < dy.size(); i++) {
-            const double ry = std::round(dy[i]), rx = std::round(dx[i]);
-            if (std::fabs(std::fabs(dy[i] - ry) - 0.5) < 1e-6 || std::fabs(std::fabs(dx[i] - rx) - 0.5) < 1e-6) int_ok = false;
-            off[i] = (uint32_t)(uint16_t)(int16_t)ry << 16 | (uint32_t)(uint16_t)(int16_t)rx;
-        }
-        if (int_ok) {
-            if ((rc = dev_alloc(h, &h->ray_off, off.size()))) return rc;
-            HIPCHK(h, hipMemcpy(h->ray_off, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        }
     }
+    HIPCHK(h, hipMemcpyAsync(h->ray_dy, dy.data(), nray * sizeof(double), hipMemcpyHostToDevice, s0));
+    HIPCHK(h, hipMemcpyAsync(h->ray_dx, dx.data(), nray * sizeof(double), hipMemcpyHostToDevice, s0));
+    // round((double)y + v) == y + round(v) for every integer |y| < 2^16 unless v is within a few ulps
+    // (of 2^17) of a half-integer; with a margin of 1e-6 the integer offsets can replace the doubles.
+    bool int_ok = h->ray_len <= 32000 && !std::getenv("ADC_INTERP_DOUBLE");
+    std::vector<uint32_t> off(nray);
+    for (size_t i = 0; int_ok && i < nray; i++) {
+        const double ry = std::round(dy[i]), rx = std::round(dx[i]);
+        if (std::fabs(std::fabs(dy[i] - ry) - 0.5) < 1e-6 || std::fabs(std::fabs(dx[i] - rx) - 0.5) < 1e-6) int_ok = false;
+        off[i] = (uint32_t)(uint16_t)(int16_t)ry << 16 | (uint32_t)(uint16_t)(int16_t)rx;
+    }
+    if (int_ok) HIPCHK(h, hipMemcpyAsync(h->ray_off, off.data(), nray * sizeof(uint32_t), hipMemcpyHostToDevice, s0));
+    else h->ray_off = nullptr;   // the kernels then use the double tables
+    // the host tables above go out of scope: wait for the uploads
+    HIPCHK(h, hipStreamSynchronize(s0));
     // penalty table (ADC/scanline_optimizer.cu:97-109)
     h->sp.P1[0] = opt->so_p1; h->sp.P1[1] = opt->so_p1 / 4; h->sp.P1[2] = opt->so_p1 / 10;
     h->sp.P2[0] = opt->so_p2; h->sp.P2[1] = opt->so_p2 / 4; h->sp.P2[2] = opt->so_p2 / 10;
 
-    h->events.resize(N_EVENTS);
-    for (auto &e : h->events) HIPCHK(h, hipEventCreate(&e));
-    if (h->debug_taps && (rc = alloc_debug(h))) return rc;
+    if (!in_arena) {
+        h->events.resize(N_EVENTS);
+        for (auto &e : h->events) HIPCHK(h, hipEventCreate(&e));
+        h->kevents.resize(N_KEV);
+        for (auto &e : h->kevents) HIPCHK(h, hipEventCreate(&e));
+        for (auto &e : h->xfer_ev) HIPCHK(h, hipEventCreate(&e));
+        if (h->debug_taps && (rc = alloc_debug(h))) return rc;
+    }
     h->pl.bgr_l = h->d_bgr_l;
     h->pl.bgr_r = h->d_bgr_r;
     h->cur_disp = h->disp_a;
@@ -272,6 +317,7 @@ inline int max_arm_of(const adc_option &o) {
 }
 
 // Enqueue the whole pipeline on stream s. d_out receives the final map (device pointer).
+// Every runtime call is checked; kernel launch failures are collected by the hipGetLastError at the end.
 int enqueue_match(adc_handle *h, const uint8_t *d_l, const uint8_t *d_r, float *d_out, hipStream_t s) {
     const Geom &g = h->g;
     const adc_option &o = h->opt;
@@ -279,13 +325,17 @@ int enqueue_match(adc_handle *h, const uint8_t *d_l, const uint8_t *d_r, float *
     Planes pl = h->pl;
     pl.bgr_l = d_l;
     pl.bgr_r = d_r;
-    const bool prof = h->profiling;
-    auto mark = [&](int i) { if (prof) hipEventRecord(h->events[i], s); };
-    auto snap = [&](void *dst, const void *src, size_t bytes) {
-        if (h->debug_taps) hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s);
-    };
+    const bool prof = h->profiling && !h->events.empty();
+#define EQ(call)                                              \
+    do {                                                      \
+        hipError_t e_ = (call);                               \
+        if (e_ != hipSuccess) return h->fail_hip(#call, e_);  \
+    } while (0)
+#define MARK(i) do { if (prof) EQ(hipEventRecord(h->events[i], s)); } while (0)
+#define KMARK(i) do { if (prof) EQ(hipEventRecord(h->kevents[i], s)); } while (0)
+#define SNAP(dst, src, bytes) do { if (h->debug_taps) EQ(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s)); } while (0)
 
-    mark(ADC_STAGE_PRE);
+    MARK(ADC_STAGE_PRE);
     launch_pack_gray(d_l, pl.pix_l, pl.gray_l, g.W, g.H, s);
     launch_pack_gray(d_r, pl.pix_r, pl.gray_r, g.W, g.H, s);
     launch_census(pl.gray_l, pl.cen_l, g.W, g.H, s);
@@ -300,51 +350,61 @@ int enqueue_match(adc_handle *h, const uint8_t *d_l, const uint8_t *d_r, float *
     // materialised (ComputeCostCuda as a kernel of its own) when its tap is wanted or the pass cannot hold it.
     const int cap = max_arm_of(o);
     const bool fuse_cost = !h->debug_taps && h->agg_variant == 0 && aggregate_cost_fusion_supported(g, cap);
-    mark(ADC_STAGE_COST);
+    MARK(ADC_STAGE_COST);
+    KMARK(ADC_KERNEL_COST);
     if (!fuse_cost) launch_cost_init(pl, g, h->lut_ad, h->lut_cen, h->vol_b, s);
-    snap(h->snap_init, h->vol_b, nvol * sizeof(float));
+    SNAP(h->snap_init, h->vol_b, nvol * sizeof(float));
 
     // CrossAggregator::Aggregate: 4 iterations, horizontal-first on even ones (ADC/cost_aggregator.cu:112,440-454)
-    mark(ADC_STAGE_AGGR);
+    MARK(ADC_STAGE_AGGR);
     for (int it = 0; it < 4; it++) {
         const bool hfirst = (it % 2) == 0;
+        KMARK(ADC_KERNEL_AGGR0 + 2 * it);
         if (it == 0 && fuse_cost)
             launch_aggregate_first_pass_with_cost(pl, h->lut_ad, h->lut_cen, h->vol_a, g, cap, s);
         else
             launch_aggregate_pass(h->vol_b, h->vol_a, pl.arms, nullptr, g, hfirst ? 0 : 1, cap, h->agg_variant, s);
+        KMARK(ADC_KERNEL_AGGR0 + 2 * it + 1);
         launch_aggregate_pass(h->vol_a, h->vol_b, pl.arms, hfirst ? pl.cnt_h32 : pl.cnt_v32, g, hfirst ? 1 : 0, cap,
                               h->agg_variant, s);
     }
-    snap(h->snap_aggr, h->vol_b, nvol * sizeof(float));
+    KMARK(ADC_KERNEL_SCAN0);
+    SNAP(h->snap_aggr, h->vol_b, nvol * sizeof(float));
 
     // ScanlineOptimizer::Optimize pass order and ping-pong (ADC/scanline_optimizer.cu:380-447)
-    mark(ADC_STAGE_SCAN);
+    MARK(ADC_STAGE_SCAN);
+    if (h->debug_taps) KMARK(ADC_KERNEL_SCAN0);   // after the tap copy
     launch_scanline_pass(h->vol_b, h->vol_a, pl, g, h->sp, 0, 1, nullptr, s);
+    KMARK(ADC_KERNEL_SCAN0 + 1);
     launch_scanline_pass(h->vol_a, h->vol_b, pl, g, h->sp, 0, 0, nullptr, s);
+    KMARK(ADC_KERNEL_SCAN0 + 2);
     launch_scanline_pass(h->vol_b, h->vol_a, pl, g, h->sp, 1, 1, nullptr, s);
+    KMARK(ADC_KERNEL_SCAN0 + 3);
     // the last pass also produces the left-view WTA map while each pixel's final costs are in registers
     launch_scanline_pass(h->vol_a, h->vol_b, pl, g, h->sp, 1, 0, h->disp_a, s);
 
-    mark(ADC_STAGE_WTA);
+    MARK(ADC_STAGE_WTA);
+    KMARK(ADC_KERNEL_WTA_RIGHT);
     launch_wta_right(h->vol_b, h->disp_r, g, s);
-    snap(h->snap_wta_l, h->disp_a, npx * sizeof(float));
+    KMARK(ADC_KERNEL_COUNT_);
+    SNAP(h->snap_wta_l, h->disp_a, npx * sizeof(float));
 
     // MultiStepRefiner::Refine (ADC/multistep_refiner.cu:283-371)
-    mark(ADC_STAGE_REFINE);
+    MARK(ADC_STAGE_REFINE);
     float *cur = h->disp_a, *oth = h->disp_b;
     if (o.do_lr_check) {
-        launch_outlier(cur, h->disp_r, oth, h->occ, h->mis, h->binmap, h->list_mis, h->list_occ, h->counters, g,
-                       o.lrcheck_thres, s);
+        EQ(launch_outlier(cur, h->disp_r, oth, h->occ, h->mis, h->binmap, h->list_mis, h->list_occ, h->counters, g,
+                          o.lrcheck_thres, s));
         std::swap(cur, oth);
     } else {
-        launch_clear_masks(h->occ, h->mis, h->counters, npx, s);
+        EQ(launch_clear_masks(h->occ, h->mis, h->counters, npx, s));
     }
-    snap(h->snap_outlier, cur, npx * sizeof(float));
-    snap(h->snap_occ, h->occ, npx);
-    snap(h->snap_mis, h->mis, npx);
+    SNAP(h->snap_outlier, cur, npx * sizeof(float));
+    SNAP(h->snap_occ, h->occ, npx);
+    SNAP(h->snap_mis, h->mis, npx);
     if (o.do_filling) {  // drives both voting and interpolation (ADC/ADCensusStereo.cu:195-196)
         if (h->vote_stamp > 0xffffff00u) {   // stamps would wrap: start over
-            hipMemsetAsync(h->tile_stamp, 0, (size_t)vote_tiles_w(g.W) * vote_tiles_h(g.H) * sizeof(uint32_t), s);
+            EQ(hipMemsetAsync(h->tile_stamp, 0, (size_t)vote_tiles_w(g.W) * vote_tiles_h(g.H) * sizeof(uint32_t), s));
             h->vote_stamp = 16;
         }
         const uint32_t stamp0 = h->vote_stamp;
@@ -364,27 +424,30 @@ int enqueue_match(adc_handle *h, const uint8_t *d_l, const uint8_t *d_r, float *
             n_mis = h->counters + 4 + 2 * it; n_occ = h->counters + 5 + 2 * it;
         }
     }
-    snap(h->snap_voting, cur, npx * sizeof(float));
+    SNAP(h->snap_voting, cur, npx * sizeof(float));
     if (o.do_filling) {
-        launch_interpolate(cur, h->occ, h->mis, h->list_mis, h->list_occ, h->list2_mis, h->list2_occ, h->counters, h->newval, pl.pix_l,
-                           h->ray_dy, h->ray_dx, h->ray_off, g, h->ray_len, s);
+        EQ(launch_interpolate(cur, h->occ, h->mis, h->list_mis, h->list_occ, h->list2_mis, h->list2_occ, h->counters, h->newval, pl.pix_l,
+                              h->ray_dy, h->ray_dx, h->ray_off, g, h->ray_len, s));
     }
-    snap(h->snap_interp, cur, npx * sizeof(float));
+    SNAP(h->snap_interp, cur, npx * sizeof(float));
     if (o.do_discontinuity_adjustment) {
         launch_edge_detect(cur, h->edge, g.W, g.H, 5.0f, s);
         launch_edge_adjust(cur, oth, h->vol_b, h->edge, g, s);
         std::swap(cur, oth);
     } else {
-        hipMemsetAsync(h->edge, 0, npx, s);
+        EQ(hipMemsetAsync(h->edge, 0, npx, s));
     }
     h->cur_disp = cur;
     launch_median3(cur, h->disp_final, g.W, g.H, s);
     if (d_out && d_out != h->disp_final)
-        hipMemcpyAsync(d_out, h->disp_final, npx * sizeof(float), hipMemcpyDeviceToDevice, s);
-    mark(ADC_STAGE_TOTAL);
+        EQ(hipMemcpyAsync(d_out, h->disp_final, npx * sizeof(float), hipMemcpyDeviceToDevice, s));
+    MARK(ADC_STAGE_TOTAL);
     h->have_times = prof;
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return h->fail_hip("kernel launch", e);
+    EQ(hipGetLastError());
+#undef EQ
+#undef MARK
+#undef KMARK
+#undef SNAP
     return ADC_OK;
 }
 
@@ -451,21 +514,52 @@ int adc_match_device(adc_handle *h, const uint8_t *d_left, const uint8_t *d_righ
     return enqueue_match(h, d_left, d_right, d_disp, s);
 }
 
+// true when p is host memory the GPU can copy from / to directly (hipHostMalloc or hipHostRegister)
+static bool is_pinned_host(const void *p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();   // an ordinary malloc pointer: not an error of ours
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
 int adc_match(adc_handle *h, const uint8_t *left, const uint8_t *right, float *disp) {
     if (!h) return ADC_ERR_ARG;
     if (!h->initialized) return h->fail(ADC_ERR_NOT_INIT, "adc_match: handle not initialised");
+    if (h->arena) return h->fail(ADC_ERR_ARG, "adc_match: not available on the static-scratch context");
     if (!left || !right || !disp) return h->fail(ADC_ERR_ARG, "adc_match: null pointer");
     HIPCHK(h, hipSetDevice(h->device));
     const size_t npx = (size_t)h->g.W * h->g.H;
-    std::memcpy(h->h_bgr_l, left, npx * 3);
-    std::memcpy(h->h_bgr_r, right, npx * 3);
-    HIPCHK(h, hipMemcpyAsync(h->d_bgr_l, h->h_bgr_l, npx * 3, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_bgr_r, h->h_bgr_r, npx * 3, hipMemcpyHostToDevice, h->stream));
+    const bool prof = h->profiling;
+    typedef std::chrono::steady_clock clk;
+    // Pageable caller memory goes through the handle's pinned staging buffers; pinned caller memory is the
+    // DMA source / target itself (no host copy on either side).
+    const bool pin_in = is_pinned_host(left) && is_pinned_host(right), pin_out = is_pinned_host(disp);
+    const uint8_t *src_l = left, *src_r = right;
+    const auto t0 = clk::now();
+    if (!pin_in) {
+        std::memcpy(h->h_bgr_l, left, npx * 3);
+        std::memcpy(h->h_bgr_r, right, npx * 3);
+        src_l = h->h_bgr_l; src_r = h->h_bgr_r;
+    }
+    const auto t1 = clk::now();
+    if (prof) HIPCHK(h, hipEventRecord(h->xfer_ev[0], h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_bgr_l, src_l, npx * 3, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_bgr_r, src_r, npx * 3, hipMemcpyHostToDevice, h->stream));
+    if (prof) HIPCHK(h, hipEventRecord(h->xfer_ev[1], h->stream));
     int rc = enqueue_match(h, h->d_bgr_l, h->d_bgr_r, h->disp_final, h->stream);
-    if (rc != ADC_OK) return rc;
-    HIPCHK(h, hipMemcpyAsync(h->h_disp, h->disp_final, npx * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (rc != ADC_OK) { hipStreamSynchronize(h->stream); return rc; }
+    if (prof) HIPCHK(h, hipEventRecord(h->xfer_ev[2], h->stream));
+    HIPCHK(h, hipMemcpyAsync(pin_out ? disp : h->h_disp, h->disp_final, npx * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (prof) HIPCHK(h, hipEventRecord(h->xfer_ev[3], h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    std::memcpy(disp, h->h_disp, npx * sizeof(float));
+    const auto t2 = clk::now();
+    if (!pin_out) std::memcpy(disp, h->h_disp, npx * sizeof(float));
+    const auto t3 = clk::now();
+    h->host_ms[0] = pin_in ? 0.0f : std::chrono::duration<float, std::milli>(t1 - t0).count();
+    h->host_ms[1] = pin_out ? 0.0f : std::chrono::duration<float, std::milli>(t3 - t2).count();
+    h->have_xfer = prof;
     return ADC_OK;
 }
 
@@ -506,13 +600,38 @@ int adc_stage_times(adc_handle *h, float *ms, int n) {
     return ADC_OK;
 }
 
+int adc_kernel_times(adc_handle *h, float *ms, int n) {
+    if (!h || !ms || n < 0) return ADC_ERR_ARG;
+    if (!h->initialized) return h->fail(ADC_ERR_NOT_INIT, "adc_kernel_times: handle not initialised");
+    if (!h->have_times) return h->fail(ADC_ERR_ARG, "adc_kernel_times: no profiled match has run");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipEventSynchronize(h->events[ADC_STAGE_TOTAL]));
+    for (int i = 0; i < n && i < ADC_KERNEL_COUNT_; i++)
+        HIPCHK(h, hipEventElapsedTime(&ms[i], h->kevents[i], h->kevents[i + 1]));
+    return ADC_OK;
+}
+
 int adc_aggr_kernel_stats(adc_handle *h, int *launches, float *total_ms) {
     if (!h) return ADC_ERR_ARG;
-    float t[ADC_STAGE_COUNT_];
-    int rc = adc_stage_times(h, t, ADC_STAGE_COUNT_);
+    float t[ADC_KERNEL_COUNT_];
+    int rc = adc_kernel_times(h, t, ADC_KERNEL_COUNT_);
     if (rc != ADC_OK) return rc;
+    float sum = 0.0f;
+    for (int i = 0; i < N_AGG_PASSES; i++) sum += t[ADC_KERNEL_AGGR0 + i];
     if (launches) *launches = N_AGG_PASSES;
-    if (total_ms) *total_ms = t[ADC_STAGE_AGGR];
+    if (total_ms) *total_ms = sum;
+    return ADC_OK;
+}
+
+int adc_transfer_times(adc_handle *h, float *ms, int n) {
+    if (!h || !ms || n < 0) return ADC_ERR_ARG;
+    if (!h->initialized) return h->fail(ADC_ERR_NOT_INIT, "adc_transfer_times: handle not initialised");
+    if (!h->have_xfer) return h->fail(ADC_ERR_ARG, "adc_transfer_times: no profiled adc_match has run");
+    HIPCHK(h, hipSetDevice(h->device));
+    float v[4] = {h->host_ms[0], 0.0f, 0.0f, h->host_ms[1]};
+    HIPCHK(h, hipEventElapsedTime(&v[1], h->xfer_ev[0], h->xfer_ev[1]));
+    HIPCHK(h, hipEventElapsedTime(&v[2], h->xfer_ev[2], h->xfer_ev[3]));
+    for (int i = 0; i < n && i < 4; i++) ms[i] = v[i];
     return ADC_OK;
 }
 
@@ -594,12 +713,13 @@ int adc_get_buffer(adc_handle *h, adc_buffer_id id, void *dst, size_t bytes) {
 
 namespace {
 
-// One device's share of a batch (pairs first, first + stride, ...), pipelined: while the GPU matches pair k
-// the host thread copies pair k+1 into pinned memory and queues its upload, and pair k-1's result travels
-// back and is copied out. Two slots of staging buffers; three streams (upload, the handle's compute stream,
-// download) ordered by events. Per frame the GPU then sees only its own 13 ms, not the 2 x 6.2 MB in and
-// 8.3 MB out that a synchronous adc_match adds in front of and behind them.
-int run_pipelined(adc_handle *h, const adc_batch_desc *d, int first, int stride) {
+// One device's share of a batch, pipelined: while the GPU matches pair k the host thread copies pair k+1
+// into pinned memory and queues its upload, and pair k-1's result travels back and is copied out. Two slots
+// of staging buffers; three streams (upload, the handle's compute stream, download) ordered by events. Per
+// frame the GPU then sees only its own match time, not the 2 x 6.2 MB in and 8.3 MB out that a synchronous
+// adc_match adds in front of and behind it. Pairs are drawn from the counter `next`, which all the devices
+// of the call share: a device that finishes early takes the next pair instead of waiting for its turn.
+int run_pipelined(adc_handle *h, const adc_batch_desc *d, std::atomic<int> *next) {
     const size_t npx = (size_t)h->g.W * h->g.H;
     HIPCHK(h, hipSetDevice(h->device));
     struct Slot {
@@ -610,7 +730,11 @@ int run_pipelined(adc_handle *h, const adc_batch_desc *d, int first, int stride)
     } slot[2];
     hipStream_t s_in = nullptr, s_out = nullptr;
     int rc = ADC_OK;
+    // nothing may still be running on the staging buffers or the events when they go away
     auto cleanup = [&]() {
+        if (s_in) hipStreamSynchronize(s_in);
+        hipStreamSynchronize(h->stream);
+        if (s_out) hipStreamSynchronize(s_out);
         if (s_in) hipStreamDestroy(s_in);
         if (s_out) hipStreamDestroy(s_out);
         for (Slot &q : slot) {
@@ -619,10 +743,26 @@ int run_pipelined(adc_handle *h, const adc_batch_desc *d, int first, int stride)
             if (q.out) hipEventDestroy(q.out);
         }
     };
+    auto finish = [&](Slot &q) -> int {   // pair q.pair: wait for its download, hand the map to the caller
+        if (q.pair < 0) return ADC_OK;
+        hipError_t e = hipEventSynchronize(q.out);
+        if (e != hipSuccess) { q.pair = -1; return h->fail_hip("hipEventSynchronize", e); }
+        std::memcpy(d->disp_left[q.pair], q.h_o, npx * sizeof(float));
+        q.pair = -1;
+        return ADC_OK;
+    };
+    // on a failure: pairs whose download was already queued are still handed over, then everything is drained
+    auto bail = [&](int code) {
+        std::string keep = h->err;
+        for (Slot &q : slot) (void)finish(q);
+        cleanup();
+        h->err = keep;
+        return code;
+    };
 #define PIPE(call)                                             \
     do {                                                       \
         hipError_t e_ = (call);                                \
-        if (e_ != hipSuccess) { cleanup(); return h->fail_hip(#call, e_); } \
+        if (e_ != hipSuccess) return bail(h->fail_hip(#call, e_)); \
     } while (0)
     PIPE(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
     PIPE(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
@@ -633,7 +773,7 @@ int run_pipelined(adc_handle *h, const adc_batch_desc *d, int first, int stride)
         if ((rc = dev_alloc(h, &h->pipe_d_o[0], npx)) || (rc = dev_alloc(h, &h->pipe_d_o[1], npx)) ||
             (rc = dev_alloc(h, &h->pipe_d_l, npx * 3)) || (rc = dev_alloc(h, &h->pipe_d_r, npx * 3)) ||
             (rc = host_alloc(h, &h->pipe_h_l, npx * 3)) || (rc = host_alloc(h, &h->pipe_h_r, npx * 3)) ||
-            (rc = host_alloc(h, &h->pipe_h_o, npx))) { cleanup(); return rc; }
+            (rc = host_alloc(h, &h->pipe_h_o, npx))) return bail(rc);
     }
     slot[0].d_o = h->pipe_d_o[0];
     slot[1].h_l = h->pipe_h_l; slot[1].h_r = h->pipe_h_r; slot[1].h_o = h->pipe_h_o;
@@ -643,42 +783,32 @@ int run_pipelined(adc_handle *h, const adc_batch_desc *d, int first, int stride)
         PIPE(hipEventCreateWithFlags(&q.done, hipEventDisableTiming));
         PIPE(hipEventCreateWithFlags(&q.out, hipEventDisableTiming));
     }
-    auto finish = [&](Slot &q) -> int {   // pair q.pair: wait for its download, hand the map to the caller
-        if (q.pair < 0) return ADC_OK;
-        hipError_t e = hipEventSynchronize(q.out);
-        if (e != hipSuccess) return h->fail_hip("hipEventSynchronize", e);
-        std::memcpy(d->disp_left[q.pair], q.h_o, npx * sizeof(float));
-        q.pair = -1;
-        return ADC_OK;
-    };
     int k = 0;
-    for (int i = first; i < d->n_pairs; i += stride, k++) {
+    for (int i; (i = next->fetch_add(1)) < d->n_pairs; k++) {
         Slot &q = slot[k & 1];
         // the slot's previous pair (k-2) was finished at the end of iteration k-1, so every buffer of it is free
-        if (!d->left_bgr[i] || !d->right_bgr[i] || !d->disp_left[i]) { rc = h->fail(ADC_ERR_ARG, "adc_match_batch: null pointer in pair " + std::to_string(i)); break; }
+        if (!d->left_bgr[i] || !d->right_bgr[i] || !d->disp_left[i])
+            return bail(h->fail(ADC_ERR_ARG, "adc_match_batch: null pointer in pair " + std::to_string(i)));
         std::memcpy(q.h_l, d->left_bgr[i], npx * 3);
         std::memcpy(q.h_r, d->right_bgr[i], npx * 3);
         PIPE(hipMemcpyAsync(q.d_l, q.h_l, npx * 3, hipMemcpyHostToDevice, s_in));
         PIPE(hipMemcpyAsync(q.d_r, q.h_r, npx * 3, hipMemcpyHostToDevice, s_in));
         PIPE(hipEventRecord(q.in, s_in));
         PIPE(hipStreamWaitEvent(h->stream, q.in, 0));
-        if ((rc = enqueue_match(h, q.d_l, q.d_r, q.d_o, h->stream)) != ADC_OK) break;
+        if ((rc = enqueue_match(h, q.d_l, q.d_r, q.d_o, h->stream)) != ADC_OK) return bail(rc);
         PIPE(hipEventRecord(q.done, h->stream));
         PIPE(hipStreamWaitEvent(s_out, q.done, 0));
         PIPE(hipMemcpyAsync(q.h_o, q.d_o, npx * sizeof(float), hipMemcpyDeviceToHost, s_out));
         PIPE(hipEventRecord(q.out, s_out));
         q.pair = i;
         // while the GPU works on pair k, hand back pair k-1
-        if ((rc = finish(slot[(k + 1) & 1])) != ADC_OK) break;
+        if ((rc = finish(slot[(k + 1) & 1])) != ADC_OK) return bail(rc);
     }
-    if (rc == ADC_OK) rc = finish(slot[(k + 1) & 1]);
-    if (rc == ADC_OK) rc = finish(slot[k & 1]);
-    hipStreamSynchronize(s_in);
-    hipStreamSynchronize(h->stream);
-    hipStreamSynchronize(s_out);
+    if ((rc = finish(slot[(k + 1) & 1])) != ADC_OK) return bail(rc);
+    if ((rc = finish(slot[k & 1])) != ADC_OK) return bail(rc);
 #undef PIPE
     cleanup();
-    return rc;
+    return ADC_OK;
 }
 
 }  // namespace
@@ -691,18 +821,31 @@ int adc_match_batch(const adc_batch_desc *d) {
         return ADC_ERR_ARG;
     }
     const int nd = d->n_devices;
+    if (d->handles) {   // the caller's handles: each must sit on its device, initialised for this frame size and option
+        for (int di = 0; di < nd; di++) {
+            const adc_handle *h = d->handles[di];
+            if (!h || !h->initialized || h->arena || h->device != d->devices[di] || h->g.W != d->width || h->g.H != d->height ||
+                std::memcmp(&h->opt, &d->option, sizeof(adc_option)) != 0) {
+                g_thread_error = "adc_match_batch: handles[" + std::to_string(di) + "] is not initialised for this device, size and option";
+                return ADC_ERR_ARG;
+            }
+            for (int dj = 0; dj < di; dj++)
+                if (d->handles[dj] == h) { g_thread_error = "adc_match_batch: the same handle twice"; return ADC_ERR_ARG; }
+        }
+    }
     std::vector<int> rcs(nd, ADC_OK);
     std::vector<std::string> errs(nd);
     std::vector<std::thread> threads;
+    std::atomic<int> next(0);
     for (int di = 0; di < nd; di++) {
         if (di >= d->n_pairs) break;   // fewer pairs than devices: the rest would only allocate and free
         threads.emplace_back([&, di]() {
-            adc_handle *h = adc_create(d->devices[di]);
+            adc_handle *h = d->handles ? d->handles[di] : adc_create(d->devices[di]);
             if (!h) { rcs[di] = ADC_ERR_NOMEM; errs[di] = "adc_create failed"; return; }
-            int rc = adc_initialize(h, d->width, d->height, &d->option);
-            if (rc == ADC_OK) rc = run_pipelined(h, d, di, nd);
+            int rc = d->handles ? ADC_OK : adc_initialize(h, d->width, d->height, &d->option);
+            if (rc == ADC_OK) rc = run_pipelined(h, d, &next);
             if (rc != ADC_OK) { rcs[di] = rc; errs[di] = h->err; }
-            adc_destroy(h);
+            if (!d->handles) adc_destroy(h);
         });
     }
     for (auto &t : threads) t.join();

@@ -19,6 +19,7 @@ struct Geom {
     int D;   // dmax - dmin
     int Dp;  // internal stride of the disparity axis
     int NV;  // disparities per lane in the wave-per-pixel kernels: 64*NV >= D
+    int simds;  // SIMDs of the handle's device (4 per compute unit): how many one-wave scanlines run side by side
 };
 
 // Per-pixel 2-D planes living in HBM for one handle.
@@ -47,6 +48,9 @@ void launch_cost_init(const Planes &p, const Geom &g, const float *lut_ad, const
 void launch_census_to_u64(const uint32_t *c32, uint64_t *c64, size_t n, hipStream_t s);
 
 // --- adc_aggregate.hip -------------------------------------------------------------------------
+// Allows every aggregation kernel its dynamic LDS on the CURRENT device (more than the default 64 KB for some
+// instantiations). Called once per handle from adc_initialize, after hipSetDevice.
+hipError_t aggregate_setup_device();
 // One directional pass: dst[p][k] = sum over the arm span of src (optionally / cnt[p]).
 // vertical = 0: span along x (left/right arms); 1: along y (top/bottom arms). cnt == nullptr: no division.
 // variant: 0 = ring kernel (LDS), 1 = direct-global fallback.
@@ -59,6 +63,7 @@ void launch_aggregate_first_pass_with_cost(const Planes &p, const float *lut_ad,
                                            const Geom &g, int max_arm, hipStream_t s);
 
 // --- adc_scanline.hip --------------------------------------------------------------------------
+hipError_t scanline_setup_device();   // as aggregate_setup_device, for the scanline kernels
 // One directional scanline pass (src -> dst). Ptab = {P1[0..2], P2[0..2]} indexed by how many of
 // (d1,d2) reach tso.
 struct ScanParams { float P1[3]; float P2[3]; };
@@ -81,10 +86,11 @@ struct RefineBufs {
     float *newval;                   // one pending value per list entry (mis list first, then occ)
     const double *ray_dy, *ray_dx;   // [16][maxlen] products m*sin, m*cos
 };
-void launch_outlier(const float *dl, const float *dr, float *out, uint8_t *occ, uint8_t *mis, short *binmap,
-                    uint32_t *list_mis, uint32_t *list_occ, uint32_t *counters,
-                    const Geom &g, float thres, hipStream_t s);
-void launch_clear_masks(uint8_t *occ, uint8_t *mis, uint32_t *counters, size_t n, hipStream_t s);
+// (launchers that also enqueue memsets return the first failing runtime call's status)
+hipError_t launch_outlier(const float *dl, const float *dr, float *out, uint8_t *occ, uint8_t *mis, short *binmap,
+                          uint32_t *list_mis, uint32_t *list_occ, uint32_t *counters,
+                          const Geom &g, float thres, hipStream_t s);
+hipError_t launch_clear_masks(uint8_t *occ, uint8_t *mis, uint32_t *counters, size_t n, hipStream_t s);
 // counters: [0] mismatch, [1] occlusion entries found by the outlier check; [2], [3] entries handed to the
 // interpolation; [4 + p] entries still open after voting pass p (0..9)
 #define ADC_NUM_COUNTERS 16
@@ -96,7 +102,7 @@ int vote_tiles_h(int H);
 void launch_region_voting_pass(float *disp, short *binmap, uint8_t *mask, const uint32_t *list, const uint32_t *count,
                                uint32_t *out_list, uint32_t *out_count, float *newval, const uint32_t *arms, uint32_t *tile_stamp, uint32_t stamp0, int pass,
                                int cap, const Geom &g, int tau_s, float tau_h, hipStream_t s);
-void launch_interpolate(float *disp, const uint8_t *occ, const uint8_t *mis,
+hipError_t launch_interpolate(float *disp, const uint8_t *occ, const uint8_t *mis,
                         const uint32_t *list_mis, const uint32_t *list_occ, uint32_t *list2_mis, uint32_t *list2_occ,
                         uint32_t *counters, float *newval, const uint32_t *pix_l, const double *ray_dy,
                         const double *ray_dx, const uint32_t *ray_off /* may be null */, const Geom &g, int maxlen,

@@ -93,19 +93,22 @@ k_outlier(const float *__restrict__ dl, const float *__restrict__ dr, float *__r
     if (is_occ) list_occ[s_off[1][wave] + (uint32_t)__popcll(m_occ & below)] = (uint32_t)i;
 }
 
-void launch_outlier(const float *dl, const float *dr, float *out, uint8_t *occ, uint8_t *mis, short *binmap,
-                    uint32_t *list_mis, uint32_t *list_occ, uint32_t *counters,
-                    const Geom &g, float thres, hipStream_t s) {
-    hipMemsetAsync(counters, 0, ADC_NUM_COUNTERS * sizeof(uint32_t), s);
+hipError_t launch_outlier(const float *dl, const float *dr, float *out, uint8_t *occ, uint8_t *mis, short *binmap,
+                          uint32_t *list_mis, uint32_t *list_occ, uint32_t *counters,
+                          const Geom &g, float thres, hipStream_t s) {
+    const hipError_t e = hipMemsetAsync(counters, 0, ADC_NUM_COUNTERS * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
     dim3 grid((g.W + 63) / 64, (g.H + OUT_WAVES - 1) / OUT_WAVES);
     k_outlier<<<grid, dim3(64 * OUT_WAVES), 0, s>>>(dl, dr, out, occ, mis, binmap, list_mis, list_occ, counters,
                                                     g.W, g.H, g.dmin, g.D, thres);
+    return hipSuccess;
 }
 
-void launch_clear_masks(uint8_t *occ, uint8_t *mis, uint32_t *counters, size_t n, hipStream_t s) {
-    hipMemsetAsync(occ, 0, n, s);
-    hipMemsetAsync(mis, 0, n, s);
-    hipMemsetAsync(counters, 0, ADC_NUM_COUNTERS * sizeof(uint32_t), s);
+hipError_t launch_clear_masks(uint8_t *occ, uint8_t *mis, uint32_t *counters, size_t n, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(occ, 0, n, s);
+    if (e == hipSuccess) e = hipMemsetAsync(mis, 0, n, s);
+    if (e == hipSuccess) e = hipMemsetAsync(counters, 0, ADC_NUM_COUNTERS * sizeof(uint32_t), s);
+    return e;
 }
 
 // ---- iterative region voting (RegionVotingCuda + DeleteFilledPixel, ADC/multistep_refiner.cu:376-449)
@@ -482,12 +485,13 @@ k_apply_interp(float *__restrict__ disp, const uint32_t *__restrict__ list_mis, 
     }
 }
 
-void launch_interpolate(float *disp, const uint8_t *occ, const uint8_t *mis,
+hipError_t launch_interpolate(float *disp, const uint8_t *occ, const uint8_t *mis,
                         const uint32_t *list_mis, const uint32_t *list_occ, uint32_t *list2_mis, uint32_t *list2_occ,
                         uint32_t *counters, float *newval, const uint32_t *pix_l, const double *ray_dy,
                         const double *ray_dx, const uint32_t *ray_off, const Geom &g, int maxlen, hipStream_t s) {
     const size_t npx = (size_t)g.W * g.H;
-    hipMemsetAsync(counters + 2, 0, 2 * sizeof(uint32_t), s);
+    const hipError_t e = hipMemsetAsync(counters + 2, 0, 2 * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
     k_compact<<<dim3(1024), dim3(1024), 0, s>>>(list_mis, list_occ, mis, occ, list2_mis, list2_occ, counters);
     const size_t tab = (size_t)16 * (maxlen | 1) * sizeof(uint32_t);
 #define ADC_INTERP(I, L, LDS) k_interp<I, L><<<dim3(8192), dim3(256), LDS, s>>>( \
@@ -497,6 +501,7 @@ void launch_interpolate(float *disp, const uint8_t *occ, const uint8_t *mis,
     else ADC_INTERP(true, false, 0);
 #undef ADC_INTERP
     k_apply_interp<<<dim3(512), dim3(256), 0, s>>>(disp, list2_mis, list2_occ, counters + 2, newval, npx);
+    return hipSuccess;
 }
 
 // ---- sobel edges (EdgeDetectCuda, ADC/multistep_refiner.cu:161-180) ---------------------------------

@@ -786,19 +786,35 @@ static void launch_nv(const float *src, float *dst, float *disp, const Planes &p
     const size_t lds = (size_t)4 * C::RS * C::SLOT_B;
     const bool full = (g.D == 64 * NV) && (g.Dp == g.D);
     const uint32_t *rec = vertical ? p.rec_v : (forward ? p.rec_hf : p.rec_hb);
-    static bool attr_set = false;
-    if (!attr_set) {
-        const int cap = 96 * 1024;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scanline<NV, 0, true, WTA>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scanline<NV, 1, true, WTA>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scanline<NV, 0, false, WTA>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scanline<NV, 1, false, WTA>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        attr_set = true;
-    }
 #define ADC_SCAN(V, F) k_scanline<NV, V, F, WTA><<<grid, block, lds, s>>>(src, dst, rec, disp, g.W, g.H, g.dmin, g.D, g.Dp, forward, sp)
     if (vertical) { if (full) ADC_SCAN(1, true); else ADC_SCAN(1, false); }
     else { if (full) ADC_SCAN(0, true); else ADC_SCAN(0, false); }
 #undef ADC_SCAN
+}
+
+// The dynamic-LDS opt-in (up to 96 KB: four per-wave rings of a workgroup) of every instantiation the launchers
+// can pick, on the current device; done by every handle for its own device when it is initialised.
+template <int NV>
+static hipError_t setup_nv() {
+    hipError_t e = hipSuccess;
+    auto set = [&e](const void *f) {
+        if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    };
+#define ADC_ATTR4(K, ...) \
+    set(reinterpret_cast<const void *>(&K<NV, 0, __VA_ARGS__>)); set(reinterpret_cast<const void *>(&K<NV, 1, __VA_ARGS__>))
+    ADC_ATTR4(k_scanline, true, true); ADC_ATTR4(k_scanline, true, false);
+    ADC_ATTR4(k_scanline, false, true); ADC_ATTR4(k_scanline, false, false);
+    if constexpr (NV <= 8) { ADC_ATTR4(k_scanline_lean, true); ADC_ATTR4(k_scanline_lean, false); }
+#undef ADC_ATTR4
+    return e;
+}
+hipError_t scanline_setup_device() {
+    hipError_t e = setup_nv<1>();
+    if (e == hipSuccess) e = setup_nv<2>();
+    if (e == hipSuccess) e = setup_nv<4>();
+    if (e == hipSuccess) e = setup_nv<8>();
+    if (e == hipSuccess) e = setup_nv<16>();
+    return e;
 }
 
 static int env_int(const char *name, int dflt) {
@@ -821,13 +837,7 @@ void launch_scanline_pass(const float *src, float *dst, const Planes &p, const G
     const bool split_ok = !disp_wta && g.Dp == g.D && (g.NV == 4 || g.NV == 8) && g.D == 64 * g.NV;
     bool split = split_ok && split_env >= 2;
     if (split_ok && split_env == 1 && !vertical) {
-        static const int simds = [] {
-            int dev = 0, cus = 0;
-            if (hipGetDevice(&dev) != hipSuccess ||
-                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-                return 0;
-            return 4 * cus;
-        }();
+        const int simds = g.simds;   // of the handle's own device
         split = g.H > simds;
         if (split && g.NV == 4 && simds >= 16 && g.H <= simds + simds / 2 && env_int("ADC_SCAN_HYBRID", 1)) {
             typedef ScanCfg<4, false, HYB_RS> C;
@@ -853,11 +863,6 @@ void launch_scanline_pass(const float *src, float *dst, const Planes &p, const G
     do {                                                                                                                    \
         typedef ScanCfgSplit<N, 1, T> CL;                                                                                   \
         const size_t lds = (size_t)4 * CL::RS * CL::SLOT_B;                                                                 \
-        static bool attr_set = false;                                                                                       \
-        if (!attr_set) {                                                                                                    \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scanline_lean<N, V, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
-            attr_set = true;                                                                                                \
-        }                                                                                                                   \
         k_scanline_lean<N, V, T><<<grid, block, lds, s>>>(src, dst, rec, disp_wta, g.W, g.H, g.dmin, g.Dp, forward, sp);    \
     } while (0)
 #define ADC_LEAN(N)                                                                                                         \

@@ -324,3 +324,136 @@ def test_uhd_512_disparities(pkg, orc, synth):
     want, taps = orc.match(L, R, orc.default_option(max_disparity=512), want=["disp_right_wta"])
     assert same(dr, taps["disp_right_wta"]), describe("disp_right_wta", dr, taps["disp_right_wta"])
     assert same(a, want), describe("disp_final", a, want)
+
+
+def test_two_handles_from_two_threads(pkg, orc, synth):
+    """Two handles initialised and matching at the same time from two host threads (what adc_match_batch does with
+    one thread per device): per-device kernel set-up must not depend on which thread or handle came first.
+    256 disparities and 34-pixel arms take the kernels that need more than the default 64 KB of dynamic LDS."""
+    import threading
+    pairs = [synth.pair(95 + i, 224, 96, 256)[:2] for i in range(2)]
+    wants = [orc.match(l, r, orc.default_option(max_disparity=256))[0] for l, r in pairs]
+    outs, errs = [None, None], []
+    gate = threading.Barrier(2)
+
+    def run(i):
+        try:
+            h = pkg.ADCensusStereo(0)
+            gate.wait()
+            assert h.Initialize(224, 96, pkg.ADCensusOption(max_disparity=256)), h.last_error()
+            gate.wait()
+            for _ in range(3):
+                outs[i] = h.match(*pairs[i])
+            h.close()
+        except Exception as e:          # noqa: BLE001 -- reported by the main thread
+            errs.append(e)
+            gate.abort()
+
+    ts = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    for o, w in zip(outs, wants):
+        assert same(o, w)
+
+
+def test_support_count_wrapping_to_zero(pkg, orc):
+    """128-pixel arms on flat images: the support region of pixel (127, 127) holds 256 x 256 pixels, its 16-bit
+    count (the reference's vec_sup_count_ is uint16) wraps to 0 and the aggregated cost there is sum / 0 = +inf,
+    as in the oracle."""
+    H = W = 300
+    L = np.full((H, W, 3), 90, np.uint8)
+    R = np.full((H, W, 3), 120, np.uint8)
+    opt = dict(max_disparity=8, cross_L1=128, cross_L2=128, do_lr_check=0, do_filling=0, do_discontinuity_adjustment=0)
+    h = pkg.ADCensusStereo(0)
+    h.set_debug_taps(True)
+    assert h.Initialize(W, H, pkg.ADCensusOption(**opt)), h.last_error()
+    h.match(L, R)
+    got = {k: h.get_buffer(k) for k in ("sup_count_h", "sup_count_v", "cost_aggr")}
+    h.close()
+    _, want = orc.match(L, R, orc.default_option(**opt), want=["sup_count_h", "sup_count_v", "cost_aggr"])
+    assert got["sup_count_h"][127, 127] == 0 and want["sup_count_h"][127, 127] == 0
+    assert np.isinf(want["cost_aggr"][127, 127]).all()
+    for k in got:
+        assert same(got[k], want[k]), describe(k, got[k], want[k])
+
+
+def test_batch_with_caller_handles(pkg, orc, synth):
+    """adc_match_batch on handles the caller keeps: two calls on the same handles (nothing is created or
+    initialised by the calls), two handles on the one GPU drawing pairs from the shared counter."""
+    opt = pkg.ADCensusOption(max_disparity=32)
+    pairs = [synth.pair(150 + i, 128, 64, 32)[:2] for i in range(7)]
+    wants = [orc.match(l, r, orc.default_option(max_disparity=32))[0] for l, r in pairs]
+    hs = [pkg.ADCensusStereo(0), pkg.ADCensusStereo(0)]
+    for h in hs:
+        assert h.Initialize(128, 64, opt), h.last_error()
+    for _ in range(2):
+        disps = pkg.match_batch([p[0] for p in pairs], [p[1] for p in pairs], opt, [0, 0], handles=hs)
+        for d, w in zip(disps, wants):
+            assert same(d, w)
+    # a handle initialised for another size is refused, not used
+    assert hs[1].Reset(96, 64, opt)
+    with pytest.raises(RuntimeError, match="not initialised for this device, size and option"):
+        pkg.match_batch([p[0] for p in pairs], [p[1] for p in pairs], opt, [0, 0], handles=hs)
+    with pytest.raises(ValueError):
+        pkg.match_batch([pairs[0][0], pairs[1][0][:32]], [pairs[0][1], pairs[1][1][:32]], opt, [0])
+    for h in hs:
+        h.close()
+
+
+def test_match_from_pinned_memory_and_timers(pkg, orc, synth):
+    """adc_match on pinned caller memory (the DMA source / target itself) and on pageable memory give the same map;
+    the per-kernel and transfer timers of a profiled match are populated and consistent with the stage times."""
+    import torch
+    L, R, _ = synth.pair(160, 320, 160, 64)
+    want = orc.match(L, R, orc.default_option(max_disparity=64))[0]
+    h = pkg.ADCensusStereo(0)
+    assert h.Initialize(320, 160, pkg.ADCensusOption(max_disparity=64))
+    h.set_profiling(True)
+    pl, pr = torch.from_numpy(L).pin_memory(), torch.from_numpy(R).pin_memory()
+    pd = torch.empty((160, 320), dtype=torch.float32).pin_memory()
+    assert h.Match(pl.numpy(), pr.numpy(), pd.numpy())
+    assert same(pd.numpy(), want)
+    x = h.transfer_times()
+    assert x["host_in"] == 0.0 and x["host_out"] == 0.0 and x["h2d"] > 0 and x["d2h"] > 0
+    assert same(h.match(L, R), want)
+    x = h.transfer_times()
+    assert x["host_in"] > 0 and x["host_out"] > 0
+    k, st = h.kernel_times(), h.stage_times()
+    assert all(k["aggr%d" % i] > 0 for i in range(8)) and all(k["scan%d" % i] > 0 for i in range(4)) and k["wta_right"] > 0
+    assert sum(k["aggr%d" % i] for i in range(8)) <= st["aggr"] * 1.02 + 0.01
+    assert abs(h.aggr_kernel_stats()[1] - sum(k["aggr%d" % i] for i in range(8))) < 1e-3
+    h.close()
+
+
+def test_wrong_array_shapes_are_refused(pkg):
+    h = pkg.ADCensusStereo(0)
+    assert h.Initialize(16, 8, pkg.ADCensusOption(max_disparity=4))
+    ok = np.zeros((8, 16, 3), np.uint8)
+    out = np.zeros((8, 16), np.float32)
+    assert h.Match(ok, ok, out)
+    assert not h.Match(np.zeros((8, 16), np.uint8), ok, out)            # a gray image
+    assert not h.Match(ok, np.zeros((4, 16, 3), np.uint8), out)         # a frame of another size
+    assert not h.Match(ok, ok, np.zeros((8, 8), np.float32))            # a short output map
+    assert not h.Match(ok, ok, np.zeros((8, 16), np.float64))
+    assert h.status == pkg.ADC_ERR_ARG
+    h.close()
+
+
+def test_frame_batch_at_size_on_one_gpu(pkg, synth):
+    """The frame-batch workload on one GPU: 256 pairs of 1920x1080 with 256 disparities through adc_match_batch
+    on a handle the caller keeps (8 distinct synthetic pairs, seeds 1000..1007, taken 32 times each; the host
+    holds the 256 output maps). Every map must equal the single-Match result of its pair, and the first pair's
+    the committed oracle hash."""
+    W, H, D, NP, ND = 1920, 1080, 256, 256, 8
+    opt = pkg.ADCensusOption(max_disparity=D)
+    pairs = [synth.pair(1000 + i, W, H, D)[:2] for i in range(ND)]
+    h = pkg.ADCensusStereo(0)
+    assert h.Initialize(W, H, opt), h.last_error()
+    singles = [h.match(l, r) for l, r in pairs]
+    assert fnv1a64(singles[0]) == GOLD["synth_1000_1080p"]["hash"]["disp_final"]
+    assert len({fnv1a64(s) for s in singles}) == ND
+    disps = pkg.match_batch([pairs[i % ND][0] for i in range(NP)], [pairs[i % ND][1] for i in range(NP)], opt, [0], handles=[h])
+    h.close()
+    for i, d in enumerate(disps):
+        assert same(d, singles[i % ND]), "pair %d" % i
