@@ -197,6 +197,25 @@ typedef struct adc_batch_desc {
 } adc_batch_desc;
 int adc_match_batch(const adc_batch_desc *desc);
 
+/* adc_match_device for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc). It has no counterpart in the reference. It takes no handle and calls no
+ * hipMalloc, hipFree, stream/event creation or any other allocating routine: every intermediate buffer of the
+ * pipeline (both cost volumes, the 2-D planes, lists, tables) is laid out in one static device array of
+ * ADC_STATIC_SCRATCH_BYTES that each GPU the library runs on holds until the process ends. The caller passes the
+ * frame size and option with every call plus the device-resident inputs and output, exactly as to
+ * adc_initialize + adc_match_device, and gets bit-identical results. Frames whose buffers need more than the
+ * array (about 700 bytes per pixel at 64 disparities; every 450x375x64 Middlebury 2003 pair fits) are rejected
+ * with ADC_ERR_UNSUPPORTED and a message naming the limit. The work is enqueued on `stream` (a hipStream_t;
+ * NULL = the null stream); a call whose size or option differs from the previous call on that GPU first
+ * re-lays the array out, uploads the option's tables and waits for the stream once, later calls only enqueue.
+ * All calls on one GPU share that GPU's array, which keeps the previous call's contents (what must start at
+ * zero is cleared by the call): calls that overlap on one GPU, from any threads or streams, race.
+ * Errors: as adc_match_device; the message is read with adc_last_error(NULL) in the calling thread. */
+#define ADC_STATIC_SCRATCH_BYTES (128u * 1024u * 1024u)
+int adc_match_device_static(int device, int32_t width, int32_t height, const adc_option *opt,
+                            const uint8_t *d_left_bgr, const uint8_t *d_right_bgr, float *d_disp_left,
+                            void *stream);
+
 /* Message of the last failure on this handle ("" if none). h == NULL returns the message of the
  * last failed adc_match_batch / adc_create in this thread. Replaces CUDA_CHECK_RETURN's
  * print-and-exit (ADC/adcensus_types.h:21-32). */

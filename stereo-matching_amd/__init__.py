@@ -6,5 +6,5 @@ The directory name carries a hyphen, so import it with
 """
 from . import adcensus  # noqa: F401
 from .adcensus import (ADC_ERR_ARG, ADC_ERR_HIP, ADC_ERR_NOMEM, ADC_ERR_NOT_INIT, ADC_ERR_UNSUPPORTED, ADC_OK,  # noqa: F401
-                       ADCensusOption, ADCensusStereo, BUFFERS, EXPORTS, HARNESS_EXPORTS, KERNELS, LIB_PATH, STAGES, lib,
-                       match_batch)
+                       ADCensusOption, ADCensusStereo, BUFFERS, EXPORTS, HARNESS_EXPORTS, KERNELS, LIB_PATH, STAGES,
+                       STATIC_SCRATCH_BYTES, lib, match_batch)

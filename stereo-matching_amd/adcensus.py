@@ -76,13 +76,14 @@ BUFFERS = {
 STAGES = ["pre", "cost", "aggr", "scan", "wta", "refine", "total"]
 # adc_kernel_id: the volume kernels of one match in launch order
 KERNELS = ["cost"] + ["aggr%d" % i for i in range(8)] + ["scan%d" % i for i in range(4)] + ["wta_right"]
+STATIC_SCRATCH_BYTES = 128 * 1024 * 1024
 
 # every symbol include/adcensus.h declares
 EXPORTS = [
     "adc_default_option", "adc_create", "adc_destroy", "adc_initialize", "adc_reset", "adc_match",
     "adc_match_device", "adc_synchronize", "adc_set_debug_taps", "adc_set_profiling", "adc_stage_times",
     "adc_aggr_kernel_stats", "adc_buffer_bytes", "adc_get_buffer", "adc_match_batch", "adc_last_error",
-    "adc_kernel_times", "adc_transfer_times",
+    "adc_kernel_times", "adc_transfer_times", "adc_match_device_static",
 ]
 # ... and include/adcensus_harness.h
 HARNESS_EXPORTS = ["adc_png_read", "adc_image_free", "adc_png_write_gray", "adc_disparity_to_u8", "adc_eval_0103",
@@ -117,6 +118,8 @@ def lib():
         L.adc_aggr_kernel_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.adc_kernel_times.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.adc_transfer_times.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.adc_match_device_static.argtypes = [C.c_int, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p]
         L.adc_buffer_bytes.restype = C.c_size_t
         L.adc_buffer_bytes.argtypes = [C.c_void_p, C.c_int]
         L.adc_get_buffer.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
@@ -198,6 +201,14 @@ class ADCensusStereo:
         if not self.Match(np.ascontiguousarray(img_left, np.uint8), np.ascontiguousarray(img_right, np.uint8), disp):
             raise RuntimeError("Match failed (%d): %s" % (self.status, self.last_error()))
         return disp
+
+    @staticmethod
+    def match_device_static(device, width, height, option, d_left_ptr, d_right_ptr, d_disp_ptr, stream=None):
+        """adc_match_device_static: no handle, nothing allocated; device pointers (ints), asynchronous on `stream`."""
+        rc = lib().adc_match_device_static(int(device), int(width), int(height), C.byref(option), d_left_ptr, d_right_ptr,
+                                           d_disp_ptr, stream)
+        if rc != ADC_OK:
+            raise RuntimeError("adc_match_device_static failed (%d): %s" % (rc, lib().adc_last_error(None).decode()))
 
     def match_device(self, d_left_ptr, d_right_ptr, d_disp_ptr, stream=None):
         """Device pointers (ints) in, asynchronous on `stream` (int hipStream_t or None)."""

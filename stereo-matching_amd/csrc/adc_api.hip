@@ -23,6 +23,11 @@ enum { N_AGG_PASSES = 8, N_EVENTS = ADC_STAGE_COUNT_ };  // stage boundaries: PR
 enum { N_KEV = ADC_KERNEL_COUNT_ + 1 };                  // kernel k runs between kernel events k and k + 1
 }
 
+// Device memory of the entry point that allocates nothing (adc_match_device_static): one array per GPU the
+// library's code object is loaded on, held until the process ends. Host code never uses this name as an
+// address; it asks for the current device's copy with hipGetSymbolAddress (static_arena below).
+static __device__ __align__(256) unsigned char scratch[ADC_STATIC_SCRATCH_BYTES];
+
 struct adc_handle {
     int device = 0;
     bool initialized = false;
@@ -811,6 +816,18 @@ int run_pipelined(adc_handle *h, const adc_batch_desc *d, std::atomic<int> *next
     return ADC_OK;
 }
 
+// ---- the context that lives in the static scratch ---------------------------------------------------------
+enum { MAX_STATIC_DEVICES = 64 };
+struct StaticCtx {
+    std::mutex mu;
+    unsigned char *ptr = nullptr;     // this device's copy of `scratch`, from hipGetSymbolAddress
+    adc_handle h;                     // buffers carved from ptr; re-laid out when the frame size or the option changes
+    int32_t W = 0, H = 0;
+    adc_option opt{};
+    bool valid = false;
+};
+StaticCtx g_static[MAX_STATIC_DEVICES];
+
 }  // namespace
 
 extern "C" {
@@ -854,6 +871,52 @@ int adc_match_batch(const adc_batch_desc *d) {
             g_thread_error = "device " + std::to_string(d->devices[di]) + ": " + errs[di];
             return rcs[di];
         }
+    return ADC_OK;
+}
+
+int adc_match_device_static(int device, int32_t width, int32_t height, const adc_option *opt,
+                            const uint8_t *d_left, const uint8_t *d_right, float *d_disp, void *stream) {
+    if (device < 0 || device >= MAX_STATIC_DEVICES) { g_thread_error = "adc_match_device_static: bad device ordinal"; return ADC_ERR_ARG; }
+    if (!opt || !d_left || !d_right || !d_disp) { g_thread_error = "adc_match_device_static: null pointer"; return ADC_ERR_ARG; }
+    StaticCtx &c = g_static[device];
+    std::lock_guard<std::mutex> lock(c.mu);
+    auto fail = [&](int code) { g_thread_error = c.h.err; return code; };
+    c.h.device = device;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(c.h.fail_hip("hipSetDevice", e));
+    if (!c.ptr) {
+        // once per device, with that device current: where this GPU keeps its copy of the array
+        void *p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) return fail(c.h.fail_hip("hipGetSymbolAddress(scratch)", e != hipSuccess ? e : hipErrorInvalidSymbol));
+        c.ptr = static_cast<unsigned char *>(p);
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!c.valid || c.W != width || c.H != height || std::memcmp(&c.opt, opt, sizeof(adc_option)) != 0) {
+        // lay the buffers out anew in the scratch (it keeps the previous call's contents: do_initialize clears
+        // what must start at zero and uploads the tables for this option)
+        c.valid = false;
+        adc_handle &h = c.h;
+        h.initialized = false;
+        h.arena = c.ptr;
+        h.arena_size = ADC_STATIC_SCRATCH_BYTES;
+        h.arena_used = 0;
+        h.d_bgr_l = h.d_bgr_r = nullptr;
+        h.tap_u64 = nullptr;
+        h.profiling = h.debug_taps = false;
+        const int rc = do_initialize(&h, width, height, opt, s);
+        if (rc != ADC_OK) {
+            if (h.arena_used > h.arena_size)
+                h.err = "adc_match_device_static: a " + std::to_string(width) + "x" + std::to_string(height) + " frame with " +
+                        std::to_string((long long)opt->max_disparity - opt->min_disparity) + " disparities needs more than the " +
+                        std::to_string((size_t)ADC_STATIC_SCRATCH_BYTES) + " bytes of static scratch; use adc_initialize + adc_match_device";
+            return fail(rc);
+        }
+        c.W = width; c.H = height; c.opt = *opt;
+        c.valid = true;
+    }
+    const int rc = enqueue_match(&c.h, d_left, d_right, d_disp, s);
+    if (rc != ADC_OK) { c.valid = false; return fail(rc); }
     return ADC_OK;
 }
 
