@@ -341,12 +341,9 @@ int enqueue_match(adc_handle *h, const uint8_t *d_l, const uint8_t *d_r, float *
 #define SNAP(dst, src, bytes) do { if (h->debug_taps) EQ(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s)); } while (0)
 
     MARK(ADC_STAGE_PRE);
-    launch_pack_gray(d_l, pl.pix_l, pl.gray_l, g.W, g.H, s);
-    launch_pack_gray(d_r, pl.pix_r, pl.gray_r, g.W, g.H, s);
-    launch_census(pl.gray_l, pl.cen_l, g.W, g.H, s);
-    launch_census(pl.gray_r, pl.cen_r, g.W, g.H, s);
-    launch_step_flags(pl.pix_l, pl.step_l, g.W, g.H, o.so_tso, s);
-    launch_step_flags(pl.pix_r, pl.step_r, g.W, g.H, o.so_tso, s);
+    launch_pack_gray(d_l, d_r, pl.pix_l, pl.pix_r, pl.gray_l, pl.gray_r, g.W, g.H, s);
+    launch_census(pl.gray_l, pl.gray_r, pl.cen_l, pl.cen_r, g.W, g.H, s);
+    launch_step_flags(pl.pix_l, pl.pix_r, pl.step_l, pl.step_r, g.W, g.H, o.so_tso, s);
     launch_arms(pl.pix_l, pl.arms, g.W, g.H, o.cross_L1, o.cross_L2, o.cross_t1, o.cross_t2, s);
     launch_sup_counts(pl.arms, pl.cnt_h, pl.cnt_v, pl.cnt_h32, pl.cnt_v32, g.W, g.H, s);
     launch_scan_records(pl, g, s);
@@ -385,10 +382,17 @@ int enqueue_match(adc_handle *h, const uint8_t *d_l, const uint8_t *d_r, float *
     KMARK(ADC_KERNEL_SCAN0 + 2);
     launch_scanline_pass(h->vol_b, h->vol_a, pl, g, h->sp, 1, 1, nullptr, s);
     KMARK(ADC_KERNEL_SCAN0 + 3);
-    // the last pass also produces the left-view WTA map while each pixel's final costs are in registers
-    launch_scanline_pass(h->vol_a, h->vol_b, pl, g, h->sp, 1, 0, h->disp_a, s);
+    // The last pass also produces the left-view WTA map while each pixel's final costs are in registers -- on
+    // frames where the pass is bound by HBM traffic and the extra instructions hide (1080p: +0.03 ms against a
+    // 0.4 ms volume read). On small frames the pass is a bare serial chain per column and those instructions
+    // more than double it (450x375x64: 154 against 66 us), while reading the small volume once more is cheap.
+    const char *wta_str = std::getenv("ADC_WTA_FUSED");   // (test hook: 0 / 1 force the separate / fused form)
+    const int wta_env = wta_str ? std::atoi(wta_str) : -1;
+    const bool wta_fused = wta_env >= 0 ? wta_env != 0 : (long long)g.W * g.Dp >= 150000;
+    launch_scanline_pass(h->vol_a, h->vol_b, pl, g, h->sp, 1, 0, wta_fused ? h->disp_a : nullptr, s);
 
     MARK(ADC_STAGE_WTA);
+    if (!wta_fused) launch_wta_left(h->vol_b, h->disp_a, g, s);
     KMARK(ADC_KERNEL_WTA_RIGHT);
     launch_wta_right(h->vol_b, h->disp_r, g, s);
     KMARK(ADC_KERNEL_COUNT_);

@@ -37,9 +37,13 @@ struct Planes {
 };
 
 // --- adc_pre.hip -------------------------------------------------------------------------------
-void launch_pack_gray(const uint8_t *bgr, uint32_t *pix, uint8_t *gray, int W, int H, hipStream_t s);
-void launch_census(const uint8_t *gray, uint32_t *census, int W, int H, hipStream_t s);
-void launch_step_flags(const uint32_t *pix, uint8_t *flags, int W, int H, int tso, hipStream_t s);
+// (one launch each for both images of the pair)
+void launch_pack_gray(const uint8_t *bgr_l, const uint8_t *bgr_r, uint32_t *pix_l, uint32_t *pix_r, uint8_t *gray_l,
+                      uint8_t *gray_r, int W, int H, hipStream_t s);
+void launch_census(const uint8_t *gray_l, const uint8_t *gray_r, uint32_t *census_l, uint32_t *census_r, int W, int H,
+                   hipStream_t s);
+void launch_step_flags(const uint32_t *pix_l, const uint32_t *pix_r, uint8_t *flags_l, uint8_t *flags_r, int W, int H,
+                       int tso, hipStream_t s);
 void launch_arms(const uint32_t *pix, uint32_t *arms, int W, int H, int L1, int L2, int t1, int t2, hipStream_t s);
 void launch_sup_counts(const uint32_t *arms, uint16_t *cnt_h, uint16_t *cnt_v, uint32_t *cnt_h32, uint32_t *cnt_v32,
                        int W, int H, hipStream_t s);
@@ -75,6 +79,7 @@ void launch_scanline_pass(const float *src, float *dst, const Planes &p, const G
 
 // --- adc_wta.hip -------------------------------------------------------------------------------
 void launch_wta_right(const float *cost, float *disp_r, const Geom &g, hipStream_t s);
+void launch_wta_left(const float *cost, float *disp_l, const Geom &g, hipStream_t s);   // when not fused into the last scanline pass
 
 // --- adc_refine.hip ----------------------------------------------------------------------------
 struct RefineBufs {
@@ -111,5 +116,40 @@ void launch_edge_detect(const float *disp, uint8_t *edge, int W, int H, float th
 void launch_edge_adjust(const float *disp_in, float *disp_out, const float *cost, const uint8_t *edge,
                         const Geom &g, hipStream_t s);
 void launch_median3(const float *in, float *out, int W, int H, hipStream_t s);
+
+
+#ifdef __HIPCC__
+// ---- wave-wide reductions shared by the scanline and WTA kernels ----------------------------------------
+// min over the 64 lanes; every lane returns the result. Six DPP steps with the lane shuffle folded into
+// the v_min itself (a lane without a source keeps its value); written out because the compiler emits a
+// copy, a move-DPP, a canonicalising max and the min per step -- on the serial critical path of every
+// path pixel. A VGPR written by a VALU op needs two wait states before a DPP op reads it.
+__device__ __forceinline__ float wave_min(float v) {
+    asm volatile(
+        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"   // lane 15 of each row: row minimum
+        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xf bank_mask:0xf\n\t" // rows 1..3 fold in the previous row
+        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xf bank_mask:0xf\n\t" // lane 63: wave minimum
+        "s_nop 0"
+        : "+v"(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+__device__ __forceinline__ int wave_min_i32(int v) {
+    asm volatile(
+        "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0"
+        : "+v"(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+#endif
 
 }  // namespace adc

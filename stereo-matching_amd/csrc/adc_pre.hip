@@ -17,19 +17,24 @@ __device__ __forceinline__ int color_dist(uint32_t p, uint32_t q) {
 // ---- pack + gray ------------------------------------------------------------------------------
 // ComputeGrayCuda (ADC/cost_computor.cu:74-89): gray = uint8(r*0.299 + g*0.587 + b*0.114) in double,
 // left to right, no contraction (the library is built with -ffp-contract=off).
-__global__ void __launch_bounds__(256) k_pack_gray(const uint8_t *__restrict__ bgr, uint32_t *__restrict__ pix,
-                                                   uint8_t *__restrict__ gray, size_t n) {
+// Both images of the pair in one launch (blockIdx.y picks the image).
+__global__ void __launch_bounds__(256) k_pack_gray(const uint8_t *__restrict__ bgr_l, const uint8_t *__restrict__ bgr_r,
+                                                   uint32_t *__restrict__ pix_l, uint32_t *__restrict__ pix_r,
+                                                   uint8_t *__restrict__ gray_l, uint8_t *__restrict__ gray_r, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const bool right = blockIdx.y != 0;
+    const uint8_t *bgr = right ? bgr_r : bgr_l;
     const uint32_t b = bgr[3 * i], g = bgr[3 * i + 1], r = bgr[3 * i + 2];
-    pix[i] = b | (g << 8) | (r << 16);
+    (right ? pix_r : pix_l)[i] = b | (g << 8) | (r << 16);
     const double v = ((double)r * 0.299 + (double)g * 0.587) + (double)b * 0.114;
-    gray[i] = (uint8_t)(uint32_t)v;
+    (right ? gray_r : gray_l)[i] = (uint8_t)(uint32_t)v;
 }
 
-void launch_pack_gray(const uint8_t *bgr, uint32_t *pix, uint8_t *gray, int W, int H, hipStream_t s) {
+void launch_pack_gray(const uint8_t *bgr_l, const uint8_t *bgr_r, uint32_t *pix_l, uint32_t *pix_r, uint8_t *gray_l,
+                      uint8_t *gray_r, int W, int H, hipStream_t s) {
     const size_t n = (size_t)W * H;
-    k_pack_gray<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(bgr, pix, gray, n);
+    k_pack_gray<<<dim3((unsigned)((n + 255) / 256), 2), dim3(256), 0, s>>>(bgr_l, bgr_r, pix_l, pix_r, gray_l, gray_r, n);
 }
 
 // ---- census -----------------------------------------------------------------------------------
@@ -41,9 +46,12 @@ void launch_pack_gray(const uint8_t *bgr, uint32_t *pix, uint8_t *gray, int W, i
 #define CEN_TH 16
 #define CEN_LW (CEN_TW + 8)
 #define CEN_LH (CEN_TH + 6)
-__global__ void __launch_bounds__(256) k_census(const uint8_t *__restrict__ gray, uint32_t *__restrict__ census,
+__global__ void __launch_bounds__(256) k_census(const uint8_t *__restrict__ gray_l, const uint8_t *__restrict__ gray_r,
+                                                uint32_t *__restrict__ census_l, uint32_t *__restrict__ census_r,
                                                 int W, int H) {
     __shared__ uint8_t tile[CEN_LH][CEN_LW];
+    const uint8_t *gray = blockIdx.z ? gray_r : gray_l;     // both images of the pair in one launch
+    uint32_t *census = blockIdx.z ? census_r : census_l;
     const int x0 = blockIdx.x * CEN_TW, y0 = blockIdx.y * CEN_TH;
     for (int i = threadIdx.x; i < CEN_LH * CEN_LW; i += 256) {
         const int ly = i / CEN_LW, lx = i - ly * CEN_LW;
@@ -77,9 +85,10 @@ __global__ void __launch_bounds__(256) k_census(const uint8_t *__restrict__ gray
     }
 }
 
-void launch_census(const uint8_t *gray, uint32_t *census, int W, int H, hipStream_t s) {
-    dim3 grid((W + CEN_TW - 1) / CEN_TW, (H + CEN_TH - 1) / CEN_TH);
-    k_census<<<grid, dim3(256), 0, s>>>(gray, census, W, H);
+void launch_census(const uint8_t *gray_l, const uint8_t *gray_r, uint32_t *census_l, uint32_t *census_r, int W, int H,
+                   hipStream_t s) {
+    dim3 grid((W + CEN_TW - 1) / CEN_TW, (H + CEN_TH - 1) / CEN_TH, 2);
+    k_census<<<grid, dim3(256), 0, s>>>(gray_l, gray_r, census_l, census_r, W, H);
 }
 
 __global__ void __launch_bounds__(256) k_census_to_u64(const uint32_t *__restrict__ c32, uint64_t *__restrict__ c64, size_t n) {
@@ -95,8 +104,11 @@ void launch_census_to_u64(const uint32_t *c32, uint64_t *c64, size_t n, hipStrea
 // with so_tso (ADC/scanline_optimizer.cu:73-74,90-91,98-109). Both directions of a path see the same
 // pixel pair, so one flag per pixel pair is enough: bit0 = dist(p[y][x], p[y][x-1]) >= tso,
 // bit1 = dist(p[y][x], p[y-1][x]) >= tso.
-__global__ void __launch_bounds__(256) k_step_flags(const uint32_t *__restrict__ pix, uint8_t *__restrict__ flags,
+__global__ void __launch_bounds__(256) k_step_flags(const uint32_t *__restrict__ pix_l, const uint32_t *__restrict__ pix_r,
+                                                    uint8_t *__restrict__ flags_l, uint8_t *__restrict__ flags_r,
                                                     int W, int H, int tso) {
+    const uint32_t *pix = blockIdx.z ? pix_r : pix_l;       // both images of the pair in one launch
+    uint8_t *flags = blockIdx.z ? flags_r : flags_l;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
@@ -107,9 +119,10 @@ __global__ void __launch_bounds__(256) k_step_flags(const uint32_t *__restrict__
     if (y >= 1 && color_dist(p, pix[i - W]) >= tso) f |= 2;
     flags[i] = f;
 }
-void launch_step_flags(const uint32_t *pix, uint8_t *flags, int W, int H, int tso, hipStream_t s) {
-    dim3 grid((W + 63) / 64, (H + 3) / 4);
-    k_step_flags<<<grid, dim3(256), 0, s>>>(pix, flags, W, H, tso);
+void launch_step_flags(const uint32_t *pix_l, const uint32_t *pix_r, uint8_t *flags_l, uint8_t *flags_r, int W, int H,
+                       int tso, hipStream_t s) {
+    dim3 grid((W + 63) / 64, (H + 3) / 4, 2);
+    k_step_flags<<<grid, dim3(256), 0, s>>>(pix_l, pix_r, flags_l, flags_r, W, H, tso);
 }
 
 // ---- cross arms -------------------------------------------------------------------------------

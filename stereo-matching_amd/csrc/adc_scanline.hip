@@ -134,23 +134,6 @@ __device__ __forceinline__ float dpp_f(float old, float src) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xf, 0xf, false));
 }
 
-// min over the 64 lanes; every lane returns the result. Six DPP steps with the lane shuffle folded into
-// the v_min itself (a lane without a source keeps its value); written out because the compiler emits a
-// copy, a move-DPP, a canonicalising max and the min per step -- on the serial critical path of every
-// path pixel. A VGPR written by a VALU op needs two wait states before a DPP op reads it.
-__device__ __forceinline__ float wave_min(float v) {
-    asm volatile(
-        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"   // lane 15 of each row: row minimum
-        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xf bank_mask:0xf\n\t" // rows 1..3 fold in the previous row
-        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xf bank_mask:0xf\n\t" // lane 63: wave minimum
-        "s_nop 0"
-        : "+v"(v));
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-
 // v_min without the canonicalising v_max the compiler puts in front of fminf() operands it cannot prove to be
 // quiet: no value in these kernels is ever a NaN (finite costs and the Large_Float sentinel only).
 __device__ __forceinline__ float min_raw(float a, float b) {
@@ -234,19 +217,6 @@ template <int NV, bool WTA, int RSO = 0> struct ScanCfg {
     static constexpr int WAITN = (RS - 2) * OPS;
     static_assert(WAITN <= 63 && RS >= 3, "vmcnt is a 6-bit counter");
 };
-
-__device__ __forceinline__ int wave_min_i32(int v) {
-    asm volatile(
-        "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 0"
-        : "+v"(v));
-    return __builtin_amdgcn_readlane(v, 63);
-}
 
 // VERT = 0: wave walks row `line` along x; VERT = 1: walks column `line` along y.
 // FULL: Dp == D == 64*NV, every lane owns NV real disparities (no masking anywhere).

@@ -116,6 +116,52 @@ k_wta_right(const float *__restrict__ cost, float *__restrict__ disp, int W, int
     }
 }
 
+// Left-view winner-take-all + sub-pixel fit (ComputeDisparityCuda, ADC/ADCensusStereo.cu:200-267) as a kernel of
+// its own: one wavefront per pixel, lanes along the disparities. Used for small frames, where reading the final
+// volume once more costs less than the extra instructions the fused form puts on the serial chain of the last
+// scanline pass; large frames keep the fused form (the volume read would cost more than the hidden instructions).
+__global__ void __launch_bounds__(256)
+k_wta_left(const float *__restrict__ cost, float *__restrict__ disp, unsigned npx, int dmin, int D, int Dp) {
+    const int lane = threadIdx.x & 63;
+    const unsigned wave = blockIdx.x * 4u + (threadIdx.x >> 6), nwaves = gridDim.x * 4u;
+    constexpr int U = 4;                             // pixels per trip: their loads are in flight together
+    for (unsigned p0 = wave * U; p0 < npx; p0 += nwaves * U) {
+        float bv[U];
+        int bk[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            bv[u] = ADC_LARGE_F;                     // the reference's initial minimum: a cost has to be below it to be taken
+            bk[u] = 0x7fffffff;
+        }
+        for (int k = lane; k < D; k += 64) {
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) v[u] = (p0 + u < npx) ? cost[(size_t)(p0 + u) * Dp + k] : ADC_LARGE_F;
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (bv[u] > v[u]) { bv[u] = v[u]; bk[u] = k; }   // strict: the first minimum of this lane's disparities
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (p0 + u >= npx) break;                // uniform
+            const float m = wave_min(bv[u]);
+            const int best = wave_min_i32((bv[u] == m) ? bk[u] : 0x7fffffff);   // the first disparity at the minimum
+            if (lane == 0) {
+                const float *row = cost + (size_t)(p0 + u) * Dp;
+                float out = __int_as_float(0x7f800000);  // Invalid_Float: minimum at either end of the range
+                if (best > 0 && best < D - 1 && m < ADC_LARGE_F) out = subpixel((float)(best + dmin), row[best - 1], row[best + 1], m);
+                disp[p0 + u] = out;
+            }
+        }
+    }
+}
+
+void launch_wta_left(const float *cost, float *disp_l, const Geom &g, hipStream_t s) {
+    const unsigned npx = (unsigned)((size_t)g.W * g.H);
+    const unsigned wgs = (npx + 15) / 16;
+    k_wta_left<<<dim3(wgs < 16384u ? wgs : 16384u), dim3(256), 0, s>>>(cost, disp_l, npx, g.dmin, g.D, g.Dp);
+}
+
 void launch_wta_right(const float *cost, float *disp_r, const Geom &g, hipStream_t s) {
     dim3 grid((g.W + WR_PX - 1) / WR_PX, g.H);
     if (g.Dp % 4 == 0 && g.D % 4 == 0 && !std::getenv("ADC_WTA_SCALAR"))

@@ -100,6 +100,7 @@ int main(int argc, char **argv) {
         float rms = 0, pep = 0, mde = 0;
         adc_eval_pfm(disp.data(), gt, w, h, delta, secs, &rms, &pep, &mde);
         std::printf("\nEvalution:\n  RMS = %.3f\n  PEP = %.3f (bad %.1f)\n  Mde = %.3f\n", rms, pep, delta, mde);  // performance_eval.cpp:213
+        std::printf("RMS_exact = %.9g\nPEP_exact = %.9g\n", rms, pep);
         adc_float_free(gt);
     }
     if (!depth_path.empty()) {

@@ -137,3 +137,43 @@ def test_cli_end_to_end(pkg, orc, tmp_path):
     pep = float([l for l in p.stdout.splitlines() if l.startswith("PEP_exact")][0].split("=")[1])
     assert abs(pep - gold) < 1e-6
     assert "Evalution:" in p.stdout and "PEP = %.3f (bad 2.0)" % gold in p.stdout
+
+
+@pytest.mark.gpu
+def test_cli_2021_scene_pfm_eval_and_depth(pkg, horc, tmp_path):
+    """adc_match on the 1920x1080 Middlebury 2021 scene, 256 disparities: the map against the committed oracle
+    hash, the 2021 evaluation (PerformanceEval, performance_eval.cpp:184-215) against a PFM ground truth and the
+    depth export (Disp2Depth2 with the scene's calib.txt, main.cpp:499-551), both against the host-side oracle of
+    the harness. The reference checkout holds no 2021 ground-truth PFMs, so the ground truth is synthetic: a
+    slanted plane with a band of unknown (+inf) pixels, written with the library's own PFM writer."""
+    import json
+    from conftest import fnv1a64
+    exe = os.path.join(os.path.dirname(pkg.__file__), "bin", "adc_match")
+    assert os.path.exists(exe), "build bin/adc_match first (make -C stereo-matching_amd)"
+    d = os.path.join(DATA, "artroom1")
+    H, W = 1080, 1920
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    gt = (40.0 + 0.05 * xx + 0.02 * yy).astype(np.float32)
+    gt[100:140, :] = np.inf                                  # unknown ground truth (inf in the 2021 PFMs)
+    gt_path = str(tmp_path / "disp0.pfm")
+    pkg.adcensus.pfm_write(gt_path, gt)
+    out, raw, depth_png = str(tmp_path / "disparity.png"), str(tmp_path / "disp.f32"), str(tmp_path / "depth.png")
+    p = subprocess.run([exe, os.path.join(d, "im0.png"), os.path.join(d, "im1.png"), out, "--min", "0", "--max", "256",
+                        "--gt-pfm", gt_path, "--calib", os.path.join(d, "calib.txt"), "--depth", depth_png, "--raw", raw],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    disp = np.fromfile(raw, np.float32).reshape(H, W)
+    gold = json.load(open(os.path.join(GOLDEN, "golden.json")))["artroom1"]
+    assert fnv1a64(disp) == gold["hash"]["disp_final"]
+    assert np.array_equal(load_gray(out), horc.disparity_to_u8(disp))
+    # evaluation block
+    rms, pep, _ = horc.eval_pfm(disp, horc.pfm_read(gt_path), 2.0, 1.0)
+    lines = {l.split("=")[0].strip(): l.split("=")[1].strip() for l in p.stdout.splitlines() if "=" in l}
+    assert float(lines["PEP_exact"]) == np.float32(pep)
+    got_rms = float(lines["RMS_exact"])
+    assert (np.isinf(got_rms) and np.isinf(rms)) or abs(got_rms - rms) <= 1e-6 * abs(rms)
+    # depth export
+    f, b, doffs = pkg.adcensus.calib_read(os.path.join(d, "calib.txt"))
+    _, o_u8, o_lo, o_hi = horc.depth(disp, f, b, doffs)
+    assert np.array_equal(load_gray(depth_png), o_u8)
+    assert "max_depth%g" % o_hi in p.stdout and "min_depth%g" % o_lo in p.stdout

@@ -457,3 +457,16 @@ def test_frame_batch_at_size_on_one_gpu(pkg, synth):
     h.close()
     for i, d in enumerate(disps):
         assert same(d, singles[i % ND]), "pair %d" % i
+
+
+@pytest.mark.parametrize("fused", ["0", "1"])
+@pytest.mark.parametrize("D,dmin", [(64, 0), (200, 0), (45, 3), (2, 0)])
+def test_left_wta_fused_and_separate(pkg, orc, synth, monkeypatch, fused, D, dmin):
+    """The left-view WTA as part of the last scanline pass (large frames) and as a kernel of its own (small
+    frames) are the same bits; ADC_WTA_FUSED forces either on a small frame."""
+    monkeypatch.setenv("ADC_WTA_FUSED", fused)
+    L, R, _ = synth.pair(170, 180, 70, max(D, 8))
+    got = gpu_match(pkg, L, R, min_disparity=dmin, max_disparity=dmin + D)
+    disp, want = orc.match(L, R, orc.default_option(min_disparity=dmin, max_disparity=dmin + D), want=["disp_left_wta"])
+    assert same(got["disp_left_wta"], want["disp_left_wta"]), describe("disp_left_wta", got["disp_left_wta"], want["disp_left_wta"])
+    assert same(got["disp_final"], disp)

@@ -29,7 +29,7 @@ import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 R = [r for r in csv.DictReader(open(f)) if "adc::" in r["Kernel_Name"]]
 R.sort(key=lambda r: int(r["Start_Timestamp"]))
-starts = [i for i, r in enumerate(R) if "k_pack_gray" in r["Kernel_Name"]][::2]
+starts = [i for i, r in enumerate(R) if "k_pack_gray" in r["Kernel_Name"]]
 acc = {}
 for a, b in zip(starts[2:-1], starts[3:]):
     j = 0

@@ -13,7 +13,7 @@ python3 - "$out/kernel_trace.csv" <<'PY'
 import csv, sys
 R = [r for r in csv.DictReader(open(sys.argv[1])) if 'adc::' in r['Kernel_Name'] or 'rocclr' in r['Kernel_Name']]
 R.sort(key=lambda r: int(r['Start_Timestamp']))
-st = [i for i, r in enumerate(R) if 'k_pack_gray' in r['Kernel_Name']][::2]
+st = [i for i, r in enumerate(R) if 'k_pack_gray' in r['Kernel_Name']]
 a, b = st[10], st[30]
 fr = R[a:b]
 busy = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in fr)
