@@ -25,6 +25,7 @@
 // from HBM, not by LDS bandwidth.
 #include "adc_common.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace adc {
@@ -498,6 +499,264 @@ k_agg_pair(const float *__restrict__ src, float *__restrict__ dst, const uint32_
     }
 }
 
+// ---- two consecutive passes along the same axis in one launch -------------------------------------------
+// The eight passes of an aggregation run H V | V H | H V | V H: passes 1+2, 3+4 and 5+6 are a dividing pass
+// followed by a plain pass along the SAME axis, and along one scanline the second only needs the first one's
+// results of that scanline. k_agg_fused runs such a pair in one sweep:
+//     stage 1   A[p] = ( sum over p's arm span of src ) / count[p]        (the dividing pass)
+//     stage 2   dst[o] = sum over o's arm span of A                        (the pass that follows it)
+// with A kept in a second LDS ring instead of travelling to HBM and back (one volume read and one volume
+// write for two passes). Stage 1 runs cap + one block ahead of stage 2, so that every A a stage-2 window
+// touches was written before the previous barrier. Each sum is the same ascending sequence of additions as
+// in the unfused passes, the division is the same exact one, and A is a float either way: identical bits.
+// Both rings hold 2*cap + 2*B slots; with 128 disparities per slot that is one workgroup per CU, so the
+// kernel lives on how few instructions a wave issues per window. The window geometry of a pair of positions
+// depends on the arms only: it is worked out once per frame and axis (k_pair_desc) instead of by every
+// wave of every pass and disparity chunk.
+//
+// Pair descriptor, for the positions p (even) and p + 1 of a line. The two windows [p-neg0, p+pos0] and
+// [p+1-neg1, p+1+pos1] always form one contiguous run of ring slots: head (terms only one window has, in front
+// of the other's first term), middle (terms of both), tail (terms only one has, behind the other's last).
+//   bits  0..6   first slot of the run, as a distance below p          (0 .. 127)
+//   bits  7..13  head length      bits 14..21  middle length      bits 22..28  tail length
+//   bit   29     the head belongs to the second window      bit 30   the tail belongs to the second window
+// A lone last position (odd line length) has an empty second window: everything is head of the first.
+// {descriptor, (float)count of p, (float)count of p+1, 0} per pair, pairs of a line contiguous.
+__global__ void __launch_bounds__(256)
+k_pair_desc(const uint32_t *__restrict__ arms, const uint32_t *__restrict__ cnt_for_h, const uint32_t *__restrict__ cnt_for_v,
+            uint4 *__restrict__ desc_h, uint4 *__restrict__ desc_v, int W, int H) {
+    const int vertical = blockIdx.z;
+    const int LEN = vertical ? H : W, lines = vertical ? W : H;
+    const int npairs = (LEN + 1) >> 1;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)lines * npairs) return;
+    // consecutive threads walk along image rows in both cases (coalesced arm reads)
+    int line, pair;
+    if (vertical) { line = (int)(gid % W); pair = (int)(gid / W); }
+    else { line = (int)(gid / npairs); pair = (int)(gid - (size_t)line * npairs); }
+    const int p = 2 * pair;
+    const bool two = p + 1 < LEN;
+    const size_t i0 = vertical ? (size_t)p * W + line : (size_t)line * W + p;
+    const size_t i1 = two ? (vertical ? i0 + W : i0 + 1) : i0;
+    const uint32_t a0 = arms[i0], a1 = arms[i1];
+    const int sh_neg = vertical ? 16 : 0, sh_pos = vertical ? 24 : 8;
+    const int b0 = -(int)((a0 >> sh_neg) & 0xff), e0 = (int)((a0 >> sh_pos) & 0xff);
+    const int b1 = two ? 1 - (int)((a1 >> sh_neg) & 0xff) : e0 + 1;
+    const int e1 = two ? 1 + (int)((a1 >> sh_pos) & 0xff) : e0;
+    const bool h0 = b0 < b1, h1 = b1 < b0;
+    const int hn = h0 ? min(e0, b1 - 1) - b0 + 1 : (h1 ? min(e1, b0 - 1) - b1 + 1 : 0);
+    const int m0 = max(b0, b1), m1 = min(e0, e1);
+    const int mn = max(m1 - m0 + 1, 0);
+    const bool t0 = e0 > e1, t1 = e1 > e0;
+    const int tn = t0 ? e0 - max(b0, e1 + 1) + 1 : (t1 ? e1 - max(b1, e0 + 1) + 1 : 0);
+    const uint32_t d = (uint32_t)(-min(b0, b1)) | (uint32_t)hn << 7 | (uint32_t)mn << 14 | (uint32_t)tn << 22 |
+                       (h1 ? 1u << 29 : 0u) | (t1 ? 1u << 30 : 0u);
+    const uint32_t *cnt = vertical ? cnt_for_v : cnt_for_h;
+    const uint4 rec = make_uint4(d, __float_as_uint((float)cnt[i0]), __float_as_uint((float)cnt[i1]), 0u);
+    (vertical ? desc_v : desc_h)[(size_t)line * npairs + pair] = rec;
+}
+
+// cnt_for_h: the counts horizontal dividing passes divide by (the vertical-first order's), cnt_for_v: the others
+void launch_pair_descriptors(const uint32_t *arms, const uint32_t *cnt_for_h, const uint32_t *cnt_for_v, uint4 *desc_h,
+                             uint4 *desc_v, const Geom &g, hipStream_t s) {
+    const size_t n = std::max((size_t)g.H * ((g.W + 1) / 2), (size_t)g.W * ((g.H + 1) / 2));
+    k_pair_desc<<<dim3((unsigned)((n + 255) / 256), 1, 2), dim3(256), 0, s>>>(arms, cnt_for_h, cnt_for_v, desc_h, desc_v, g.W, g.H);
+}
+
+// n consecutive slots from byte-free float pointer q, n known to be small most of the time (heads and tails)
+template <int VEC>
+__device__ __forceinline__ void short_span(typename VecT<VEC>::T &acc, const float *q, int n) {
+    if (n == 1) group_add<VEC, 1, 1>(acc, acc, q);
+    else if (n > 1) span<VEC, 1>(acc, acc, q, 0, n);
+}
+
+// The sums of the two windows of a pair from ring `rl` (R slots); q = slot of the pair's first position.
+template <int VEC>
+__device__ __forceinline__ void desc_windows(typename VecT<VEC>::T &acc0, typename VecT<VEC>::T &acc1, const float *rl, int R,
+                                             int q, uint32_t d) {
+    typedef typename VecT<VEC>::T vec_t;
+    constexpr int SLOT = 64 * VEC;
+    const int hn = (d >> 7) & 127, mn = (d >> 14) & 255, tn = (d >> 22) & 127;
+    const bool h1 = (d >> 29) & 1, t1 = (d >> 30) & 1;
+    int u = q - (int)(d & 127);
+    if (u < 0) u += R;
+    const vec_t zero = {};
+    vec_t hd = {};
+    if (u + hn + mn + tn <= R) {
+        // the run does not cross the end of the ring (three times out of four)
+        const float *p = rl + u * SLOT;
+        short_span<VEC>(hd, p, hn);
+        acc0 = h1 ? zero : hd;
+        acc1 = h1 ? hd : zero;
+        p += hn * SLOT;
+        span<VEC, 2>(acc0, acc1, p, 0, mn);
+        p += mn * SLOT;
+        vec_t tl = t1 ? acc1 : acc0;
+        short_span<VEC>(tl, p, tn);
+        acc0 = t1 ? acc0 : tl;
+        acc1 = t1 ? tl : acc1;
+    } else {
+        range1<VEC>(hd, rl, u, hn, R);
+        acc0 = h1 ? zero : hd;
+        acc1 = h1 ? hd : zero;
+        int v = u + hn;
+        if (v >= R) v -= R;
+        range2<VEC>(acc0, acc1, rl, v, mn, R);
+        v += mn;
+        if (v >= R) v -= R;
+        vec_t tl = t1 ? acc1 : acc0;
+        range1<VEC>(tl, rl, v, tn, R);
+        acc0 = t1 ? acc0 : tl;
+        acc1 = t1 ? tl : acc1;
+    }
+}
+
+template <int VEC, bool FULLD>
+__global__ void __launch_bounds__(AGG_WAVES * 64)
+k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 *__restrict__ desc,
+            int W, int H, int Dp, int vertical, int seglen, int cap, int R) {
+    // cap: the arm cap rounded up to an even number. Segments start at multiples of B, so every pair of positions
+    // starts at an even position of the line and at an even ring slot (R is even): a pair never straddles the
+    // end of a ring or the start of a valid range, and only the last pair of a line of odd length is a lone one.
+    typedef typename VecT<VEC>::T vec_t;
+    typedef volatile vec_t __attribute__((address_space(3))) *lds_vec_ptr;
+    constexpr int SLOT = 64 * VEC;
+    constexpr int B = PAIR_B;
+    extern __shared__ __align__(16) float ring[];   // ring 1 (src): R x SLOT, then ring 2 (A): R x SLOT
+    float *const ring2 = ring + (size_t)R * SLOT;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kc = blockIdx.x * SLOT;
+    const int line = blockIdx.y;
+    const int LEN = vertical ? H : W;
+    const int s0 = blockIdx.z * seglen;
+    if (s0 >= LEN) return;
+    const int s1 = min(LEN, s0 + seglen);
+    const int lo_a = max(0, s0 - cap), hi_a = min(LEN, s1 + cap);     // stage-1 positions this segment needs (lo_a even)
+    const int lo_s = max(0, lo_a - cap), hi_s = min(LEN, hi_a + cap); // input positions those need
+    const int mstride = vertical ? W * Dp : Dp;
+    const size_t lbase = (vertical ? (size_t)line * Dp : (size_t)line * W * Dp) + (size_t)kc;
+    bool fok[VEC];
+#pragma unroll
+    for (int h = 0; h < VEC; h++) fok[h] = FULLD || kc + h * 64 + lane < Dp;
+    const float *fsrc = src + lbase + lane;
+    const bool kok = FULLD || kc + lane * VEC < Dp;
+    const float *rl1 = ring + lane * VEC, *rl2 = ring2 + lane * VEC;
+    const uint4 *dline = desc + (size_t)line * ((LEN + 1) >> 1);       // this line's pair descriptors
+
+    // Iteration j = -nlead, ..., 0, 1, ...: stage 1 on positions pa .. pa+B-1, pa = s0 + cap + B*(j+1); stage 2
+    // (j >= 0) on o0 .. o0+B-1, o0 = s0 + B*j; fills of the inputs stage 1 of iteration j+1 adds to its windows.
+    const int nlead = (2 * cap + B - 1) / B + 1;
+    int pa = s0 + cap + B * (1 - nlead);          // <= s0 - cap: the first stage-1 block starts at or before lo_a
+    // ring 1: slot 0 <-> position pa - cap of the first iteration; ring 2: slot 0 <-> the first pa
+    {
+        const int base1 = pa - cap;
+        for (int i = wave; i < 2 * cap + B; i += AGG_WAVES) {
+            const int x = base1 + i;
+            if (x >= lo_s && x < hi_s) {
+                const float *g = fsrc + (size_t)x * mstride;
+#pragma unroll
+                for (int h = 0; h < VEC; h++)
+                    if (fok[h]) ring_fill(g + h * 64, ring + i * SLOT + h * 64);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    int q1 = cap + 2 * wave;                       // ring-1 slot of this wave's first stage-1 position
+    int qf = 2 * cap + B + 2 * wave;               // ring-1 slot of this wave's first fill of the iteration
+    if (qf >= R) qf -= R;
+    int qw = 2 * wave;                             // ring-2 slot of this wave's first stage-1 position
+    int q2 = (s0 - pa) % R + 2 * wave;             // ring-2 slot of this wave's first stage-2 position (from j = 0 on)
+    if (q2 >= R) q2 -= R;
+    const ptrdiff_t blk_m = (ptrdiff_t)B * mstride;
+    const float *fill_p = fsrc + (ptrdiff_t)(pa + B + cap + 2 * wave) * mstride;   // (only dereferenced inside [lo_s, hi_s))
+    float *out_p = dst + lbase + lane * VEC + (size_t)(s0 + 2 * wave) * mstride;
+    // pair indices of this wave's stage-1 / stage-2 pair (descriptors are fetched by scalar loads one iteration
+    // ahead of their use; only indices inside the line are dereferenced)
+    int i1 = (pa >> 1) + wave, i2 = (s0 >> 1) + wave;
+    uint4 d1c = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t d2c = 0u;
+    if (pa + 2 * wave >= lo_a && pa + 2 * wave < hi_a) d1c = dline[i1];
+    if (s0 + 2 * wave < s1) d2c = dline[i2].x;
+
+    for (int o0 = s0 - B * nlead; o0 < s1; o0 += B, pa += B) {
+        const bool run2 = o0 >= s0;
+        // (a) fills for stage 1 of the next iteration (the pair's two positions; qf is even, so qf + 1 < R)
+        const int f = pa + B + cap + 2 * wave;
+        const int nfill = f + 1 < hi_s ? 2 : (f < hi_s ? 1 : 0);
+        __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            if (t < nfill) {
+                if constexpr (FULLD && VEC == 2) {
+                    ring_fill(fill_p + (ptrdiff_t)t * mstride, ring + (qf + t) * SLOT);
+                    ring_fill_hi(fill_p + (ptrdiff_t)t * mstride, ring + (qf + t) * SLOT);
+                } else {
+#pragma unroll
+                    for (int h = 0; h < VEC; h++)
+                        if (fok[h]) ring_fill(fill_p + (ptrdiff_t)t * mstride + h * 64, ring + (qf + t) * SLOT + h * 64);
+                }
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        // next iteration's descriptors
+        uint4 d1n = make_uint4(0u, 0u, 0u, 0u);
+        uint32_t d2n = d2c;
+        {
+            const int pn = pa + B + 2 * wave;
+            if (pn >= lo_a && pn < hi_a) d1n = dline[i1 + B / 2];
+            if (run2 && o0 + B + 2 * wave < s1) d2n = dline[i2 + B / 2].x;
+        }
+        // (b) stage 1: A of positions p, p + 1 into ring 2
+        {
+            const int p = pa + 2 * wave;
+            if (p >= lo_a && p < hi_a) {
+                vec_t acc0, acc1;
+                desc_windows<VEC>(acc0, acc1, rl1, R, q1, d1c.x);
+                acc0 = div_by_count<VEC>(acc0, __uint_as_float(d1c.y));
+                *(lds_vec_ptr)(uintptr_t)(rl2 + qw * SLOT) = acc0;
+                if (p + 1 < hi_a) {
+                    acc1 = div_by_count<VEC>(acc1, __uint_as_float(d1c.z));
+                    *(lds_vec_ptr)(uintptr_t)(rl2 + (qw + 1) * SLOT) = acc1;
+                }
+            }
+        }
+        // (c) stage 2: outputs o, o + 1 from ring 2 (written before the previous barrier)
+        int nstore = 0;
+        if (run2) {
+            const int o = o0 + 2 * wave;
+            if (o < s1) {
+                const bool two = o + 1 < s1;
+                vec_t acc0, acc1;
+                desc_windows<VEC>(acc0, acc1, rl2, R, q2, d2c);
+                if (kok) {
+                    *reinterpret_cast<vec_t *>(out_p) = acc0;
+                    if (two) *reinterpret_cast<vec_t *>(out_p + mstride) = acc1;
+                }
+                nstore = two ? 2 : 1;
+            }
+            q2 += B; if (q2 >= R) q2 -= R;
+            out_p += blk_m;
+            i2 += B / 2;
+        }
+        d1c = d1n;
+        d2c = d2n;
+        // (d) the fills must have landed before the next iteration reads them: in the steady state they are
+        //     older than exactly this iteration's two stores
+        if (nfill == 2 && nstore == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (nfill) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        q1 += B; if (q1 >= R) q1 -= R;
+        qf += B; if (qf >= R) qf -= R;
+        qw += B; if (qw >= R) qw -= R;
+        fill_p += blk_m;
+        i1 += B / 2;
+    }
+}
+
 // Fallback without LDS (any arm cap): one wave per (position, 64 disparities), spans re-read through
 // the caches. Same addition order.
 template <bool DIV>
@@ -614,11 +873,49 @@ static hipError_t setup_vec() {
     ADC_PAIR_ATTR(true, false, true); ADC_PAIR_ATTR(false, false, true); ADC_PAIR_ATTR(false, true, true);
     ADC_PAIR_ATTR(true, false, false); ADC_PAIR_ATTR(false, false, false); ADC_PAIR_ATTR(false, true, false);
 #undef ADC_PAIR_ATTR
+    set(reinterpret_cast<const void *>(&k_agg_fused<VEC, true>), 160 * 1024);
+    set(reinterpret_cast<const void *>(&k_agg_fused<VEC, false>), 160 * 1024);
     return e;
 }
 hipError_t aggregate_setup_device() {
     const hipError_t e = setup_vec<1>();
     return e != hipSuccess ? e : setup_vec<2>();
+}
+
+// forward declaration (defined below)
+static bool pair_kernel_ok(const Geom &g, int max_arm);
+
+// Both rings of k_agg_fused must fit one CU's LDS, and the frame must be large enough for whole-line
+// workgroups to fill the chip (a segment's lead-in recomputes 2*cap + B stage-1 positions).
+bool aggregate_pair_fusion_supported(const Geom &g, int max_arm) {
+    const char *str = std::getenv("ADC_AGG_FUSE");      // (test hook: 0 never, 2 whatever the frame size)
+    const int env = str ? std::atoi(str) : 1;
+    const int vec = (g.Dp >= 128 && g.Dp % 2 == 0) ? 2 : 1;
+    const size_t lds = (size_t)2 * (2 * ((max_arm + 1) & ~1) + 2 * PAIR_B) * 64 * vec * 4;
+    const long long chunks = (g.Dp + 64 * vec - 1) / (64 * vec);
+    const long long wgs_min = chunks * (g.W < g.H ? g.W : g.H);
+    const bool big = wgs_min >= 512 && (long long)g.W * g.H * g.Dp >= (32ll << 20);
+    return env && pair_kernel_ok(g, max_arm) && lds <= 156 * 1024 && (big || env == 2);
+}
+
+// src -> (dividing pass along the axis) -> (plain pass along the same axis) -> dst; desc: that axis's pair descriptors
+void launch_aggregate_fused_pair(const float *src, float *dst, const uint4 *desc, const Geom &g, int vertical, int max_arm,
+                                 hipStream_t s) {
+    const int vec = (g.Dp >= 128 && g.Dp % 2 == 0) ? 2 : 1;
+    const int SLOT = 64 * vec;
+    const int chunks = (g.Dp + SLOT - 1) / SLOT;
+    const int lines = vertical ? g.W : g.H;
+    const int LEN = vertical ? g.H : g.W;
+    const int cap = (max_arm + 1) & ~1;                      // even (see the kernel)
+    const int R = 2 * cap + 2 * PAIR_B;
+    const size_t lds = (size_t)2 * R * SLOT * sizeof(float);
+    int seglen = ((LEN + PAIR_B - 1) / PAIR_B) * PAIR_B;     // whole lines
+    dim3 grid(chunks, lines, (LEN + seglen - 1) / seglen), block(AGG_WAVES * 64);
+    const bool fulld = g.Dp % SLOT == 0;
+#define ADC_FUSED_GO(V_, F_) k_agg_fused<V_, F_><<<grid, block, lds, s>>>(src, dst, desc, g.W, g.H, g.Dp, vertical, seglen, cap, R)
+    if (vec == 2) { if (fulld) ADC_FUSED_GO(2, true); else ADC_FUSED_GO(2, false); }
+    else { if (fulld) ADC_FUSED_GO(1, true); else ADC_FUSED_GO(1, false); }
+#undef ADC_FUSED_GO
 }
 
 static bool pair_kernel_ok(const Geom &g, int max_arm) {

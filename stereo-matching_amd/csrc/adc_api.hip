@@ -58,6 +58,7 @@ struct adc_handle {
     Planes pl{};
     // volumes: B holds the initial cost, then every even result; A is the other ping-pong buffer
     float *vol_a = nullptr, *vol_b = nullptr;
+    float *vol_final = nullptr, *vol_aux = nullptr;   // which of the two holds the final scanline volume / the third pass's output
     float *snap_init = nullptr, *snap_aggr = nullptr;
     // tables
     float *lut_ad = nullptr, *lut_cen = nullptr;
@@ -224,6 +225,7 @@ int do_initialize(adc_handle *h, int32_t W, int32_t H, const adc_option *opt, hi
         A(h->pl.rec_hf, nrec); A(h->pl.rec_hb, nrec); A(h->pl.rec_v, nrec);
         A(h->pl.rec_rows, (size_t)3 * g.H * scan_row_dwords(g));
     }
+    A(h->pl.pair_h, (size_t)H * ((W + 1) / 2)); A(h->pl.pair_v, (size_t)W * ((H + 1) / 2));
     A(h->vol_a, nvol); A(h->vol_b, nvol);
     A(h->lut_ad, 768); A(h->lut_cen, 68);
     A(h->disp_a, npx); A(h->disp_b, npx); A(h->disp_r, npx); A(h->disp_final, npx);
@@ -311,6 +313,8 @@ int do_initialize(adc_handle *h, int32_t W, int32_t H, const adc_option *opt, hi
     h->pl.bgr_l = h->d_bgr_l;
     h->pl.bgr_r = h->d_bgr_r;
     h->cur_disp = h->disp_a;
+    h->vol_final = h->vol_b;
+    h->vol_aux = h->vol_a;
     h->initialized = true;
     h->err.clear();
     return ADC_OK;
@@ -347,40 +351,70 @@ int enqueue_match(adc_handle *h, const uint8_t *d_l, const uint8_t *d_r, float *
     launch_arms(pl.pix_l, pl.arms, g.W, g.H, o.cross_L1, o.cross_L2, o.cross_t1, o.cross_t2, s);
     launch_sup_counts(pl.arms, pl.cnt_h, pl.cnt_v, pl.cnt_h32, pl.cnt_v32, g.W, g.H, s);
     launch_scan_records(pl, g, s);
+    const int cap = max_arm_of(o);
+    const bool fuse_pairs = h->agg_variant == 0 && aggregate_pair_fusion_supported(g, cap);
+    // horizontal dividing passes divide by the vertical-first counts, vertical ones by the horizontal-first counts
+    if (fuse_pairs) launch_pair_descriptors(pl.arms, pl.cnt_v32, pl.cnt_h32, pl.pair_h, pl.pair_v, g, s);
 
     // The initial cost volume is computed inside the first aggregation pass when that is possible; it is
     // materialised (ComputeCostCuda as a kernel of its own) when its tap is wanted or the pass cannot hold it.
-    const int cap = max_arm_of(o);
     const bool fuse_cost = !h->debug_taps && h->agg_variant == 0 && aggregate_cost_fusion_supported(g, cap);
     MARK(ADC_STAGE_COST);
     KMARK(ADC_KERNEL_COST);
     if (!fuse_cost) launch_cost_init(pl, g, h->lut_ad, h->lut_cen, h->vol_b, s);
     SNAP(h->snap_init, h->vol_b, nvol * sizeof(float));
 
-    // CrossAggregator::Aggregate: 4 iterations, horizontal-first on even ones (ADC/cost_aggregator.cu:112,440-454)
+    // CrossAggregator::Aggregate: 4 iterations, horizontal-first on even ones (ADC/cost_aggregator.cu:112,440-454):
+    // passes H, V/cntH | V, H/cntV | H, V/cntH | V, H/cntV. `cur` is the volume holding the latest result.
     MARK(ADC_STAGE_AGGR);
-    for (int it = 0; it < 4; it++) {
-        const bool hfirst = (it % 2) == 0;
-        KMARK(ADC_KERNEL_AGGR0 + 2 * it);
-        if (it == 0 && fuse_cost)
-            launch_aggregate_first_pass_with_cost(pl, h->lut_ad, h->lut_cen, h->vol_a, g, cap, s);
-        else
-            launch_aggregate_pass(h->vol_b, h->vol_a, pl.arms, nullptr, g, hfirst ? 0 : 1, cap, h->agg_variant, s);
-        KMARK(ADC_KERNEL_AGGR0 + 2 * it + 1);
-        launch_aggregate_pass(h->vol_a, h->vol_b, pl.arms, hfirst ? pl.cnt_h32 : pl.cnt_v32, g, hfirst ? 1 : 0, cap,
-                              h->agg_variant, s);
+    float *cur_v, *oth_v;
+    if (fuse_pairs) {
+        // five launches: pass 0 | passes 1+2 | 3+4 | 5+6 | pass 7 -- a dividing pass and the same-axis pass behind
+        // it share a launch and the volume between them never leaves the CU
+        KMARK(ADC_KERNEL_AGGR0);
+        if (fuse_cost) {
+            cur_v = h->vol_b; oth_v = h->vol_a;    // nothing lives in either volume yet
+            launch_aggregate_first_pass_with_cost(pl, h->lut_ad, h->lut_cen, cur_v, g, cap, s);
+        } else {
+            cur_v = h->vol_a; oth_v = h->vol_b;
+            launch_aggregate_pass(h->vol_b, cur_v, pl.arms, nullptr, g, 0, cap, 0, s);
+        }
+        for (int k = 0; k < 3; k++) {
+            const int vertical = (k % 2) == 0;
+            KMARK(ADC_KERNEL_AGGR0 + 1 + 2 * k);
+            launch_aggregate_fused_pair(cur_v, oth_v, vertical ? pl.pair_v : pl.pair_h, g, vertical, cap, s);
+            KMARK(ADC_KERNEL_AGGR0 + 2 + 2 * k);   // (the pair's second pass has no launch of its own: 0 ms)
+            std::swap(cur_v, oth_v);
+        }
+        KMARK(ADC_KERNEL_AGGR0 + 7);
+        launch_aggregate_pass(cur_v, oth_v, pl.arms, pl.cnt_v32, g, 0, cap, 0, s);
+        std::swap(cur_v, oth_v);
+    } else {
+        for (int it = 0; it < 4; it++) {
+            const bool hfirst = (it % 2) == 0;
+            KMARK(ADC_KERNEL_AGGR0 + 2 * it);
+            if (it == 0 && fuse_cost)
+                launch_aggregate_first_pass_with_cost(pl, h->lut_ad, h->lut_cen, h->vol_a, g, cap, s);
+            else
+                launch_aggregate_pass(h->vol_b, h->vol_a, pl.arms, nullptr, g, hfirst ? 0 : 1, cap, h->agg_variant, s);
+            KMARK(ADC_KERNEL_AGGR0 + 2 * it + 1);
+            launch_aggregate_pass(h->vol_a, h->vol_b, pl.arms, hfirst ? pl.cnt_h32 : pl.cnt_v32, g, hfirst ? 1 : 0, cap,
+                                  h->agg_variant, s);
+        }
+        cur_v = h->vol_b; oth_v = h->vol_a;
     }
     KMARK(ADC_KERNEL_SCAN0);
-    SNAP(h->snap_aggr, h->vol_b, nvol * sizeof(float));
+    SNAP(h->snap_aggr, cur_v, nvol * sizeof(float));
 
-    // ScanlineOptimizer::Optimize pass order and ping-pong (ADC/scanline_optimizer.cu:380-447)
+    // ScanlineOptimizer::Optimize pass order and ping-pong (ADC/scanline_optimizer.cu:380-447): the result ends
+    // in the volume the aggregation left its result in, the other one holds the third pass's output
     MARK(ADC_STAGE_SCAN);
     if (h->debug_taps) KMARK(ADC_KERNEL_SCAN0);   // after the tap copy
-    launch_scanline_pass(h->vol_b, h->vol_a, pl, g, h->sp, 0, 1, nullptr, s);
+    launch_scanline_pass(cur_v, oth_v, pl, g, h->sp, 0, 1, nullptr, s);
     KMARK(ADC_KERNEL_SCAN0 + 1);
-    launch_scanline_pass(h->vol_a, h->vol_b, pl, g, h->sp, 0, 0, nullptr, s);
+    launch_scanline_pass(oth_v, cur_v, pl, g, h->sp, 0, 0, nullptr, s);
     KMARK(ADC_KERNEL_SCAN0 + 2);
-    launch_scanline_pass(h->vol_b, h->vol_a, pl, g, h->sp, 1, 1, nullptr, s);
+    launch_scanline_pass(cur_v, oth_v, pl, g, h->sp, 1, 1, nullptr, s);
     KMARK(ADC_KERNEL_SCAN0 + 3);
     // The last pass also produces the left-view WTA map while each pixel's final costs are in registers -- on
     // frames where the pass is bound by HBM traffic and the extra instructions hide (1080p: +0.03 ms against a
@@ -389,12 +423,14 @@ int enqueue_match(adc_handle *h, const uint8_t *d_l, const uint8_t *d_r, float *
     const char *wta_str = std::getenv("ADC_WTA_FUSED");   // (test hook: 0 / 1 force the separate / fused form)
     const int wta_env = wta_str ? std::atoi(wta_str) : -1;
     const bool wta_fused = wta_env >= 0 ? wta_env != 0 : (long long)g.W * g.Dp >= 150000;
-    launch_scanline_pass(h->vol_a, h->vol_b, pl, g, h->sp, 1, 0, wta_fused ? h->disp_a : nullptr, s);
+    launch_scanline_pass(oth_v, cur_v, pl, g, h->sp, 1, 0, wta_fused ? h->disp_a : nullptr, s);
+    h->vol_final = cur_v;
+    h->vol_aux = oth_v;
 
     MARK(ADC_STAGE_WTA);
-    if (!wta_fused) launch_wta_left(h->vol_b, h->disp_a, g, s);
+    if (!wta_fused) launch_wta_left(cur_v, h->disp_a, g, s);
     KMARK(ADC_KERNEL_WTA_RIGHT);
-    launch_wta_right(h->vol_b, h->disp_r, g, s);
+    launch_wta_right(cur_v, h->disp_r, g, s);
     KMARK(ADC_KERNEL_COUNT_);
     SNAP(h->snap_wta_l, h->disp_a, npx * sizeof(float));
 
@@ -441,7 +477,7 @@ int enqueue_match(adc_handle *h, const uint8_t *d_l, const uint8_t *d_r, float *
     SNAP(h->snap_interp, cur, npx * sizeof(float));
     if (o.do_discontinuity_adjustment) {
         launch_edge_detect(cur, h->edge, g.W, g.H, 5.0f, s);
-        launch_edge_adjust(cur, oth, h->vol_b, h->edge, g, s);
+        launch_edge_adjust(cur, oth, cur_v, h->edge, g, s);
         std::swap(cur, oth);
     } else {
         EQ(hipMemsetAsync(h->edge, 0, npx, s));
@@ -689,8 +725,8 @@ int adc_get_buffer(adc_handle *h, adc_buffer_id id, void *dst, size_t bytes) {
         case ADC_BUF_SUP_COUNT_V: src = h->pl.cnt_v; break;
         case ADC_BUF_COST_INIT: vol = h->snap_init; debug_only = true; break;
         case ADC_BUF_COST_AGGR: vol = h->snap_aggr; debug_only = true; break;
-        case ADC_BUF_COST_SCAN: vol = h->vol_b; break;
-        case ADC_BUF_COST_SCAN_AUX: vol = h->vol_a; break;
+        case ADC_BUF_COST_SCAN: vol = h->vol_final; break;
+        case ADC_BUF_COST_SCAN_AUX: vol = h->vol_aux; break;
         case ADC_BUF_DISP_LEFT_WTA: src = h->snap_wta_l; debug_only = true; break;
         case ADC_BUF_DISP_RIGHT_WTA: src = h->disp_r; break;
         case ADC_BUF_DISP_OUTLIER: src = h->snap_outlier; debug_only = true; break;

@@ -34,6 +34,7 @@ struct Planes {
     uint32_t *cnt_h32, *cnt_v32;    // same counts widened to 32 bits (dword scalar loads in the aggregation kernel)
     uint32_t *rec_hf, *rec_hb, *rec_v;  // per-pixel colour-step records of the scanline passes, (2*NV+1) dwords each
     uint32_t *rec_rows;                 // per-row packed right-image step flags the records are cut from (3 families)
+    uint4 *pair_h, *pair_v;             // window descriptors of the position pairs of every row / column (fused aggregation)
 };
 
 // --- adc_pre.hip -------------------------------------------------------------------------------
@@ -65,6 +66,15 @@ void launch_aggregate_pass(const float *src, float *dst, const uint32_t *arms, c
 bool aggregate_cost_fusion_supported(const Geom &g, int max_arm);
 void launch_aggregate_first_pass_with_cost(const Planes &p, const float *lut_ad, const float *lut_cen, float *dst,
                                            const Geom &g, int max_arm, hipStream_t s);
+
+// A dividing pass and the plain pass that follows it along the same axis (passes 1+2, 3+4, 5+6 of the eight)
+// as one launch, the intermediate volume staying in LDS: only when aggregate_pair_fusion_supported().
+bool aggregate_pair_fusion_supported(const Geom &g, int max_arm);
+// per frame: the window geometry of every pair of neighbouring positions, per axis (Planes::pair_h / pair_v)
+void launch_pair_descriptors(const uint32_t *arms, const uint32_t *cnt_for_h, const uint32_t *cnt_for_v, uint4 *desc_h,
+                             uint4 *desc_v, const Geom &g, hipStream_t s);
+void launch_aggregate_fused_pair(const float *src, float *dst, const uint4 *desc, const Geom &g, int vertical, int max_arm,
+                                 hipStream_t s);
 
 // --- adc_scanline.hip --------------------------------------------------------------------------
 hipError_t scanline_setup_device();   // as aggregate_setup_device, for the scanline kernels

@@ -470,3 +470,28 @@ def test_left_wta_fused_and_separate(pkg, orc, synth, monkeypatch, fused, D, dmi
     disp, want = orc.match(L, R, orc.default_option(min_disparity=dmin, max_disparity=dmin + D), want=["disp_left_wta"])
     assert same(got["disp_left_wta"], want["disp_left_wta"]), describe("disp_left_wta", got["disp_left_wta"], want["disp_left_wta"])
     assert same(got["disp_final"], disp)
+
+
+@pytest.mark.parametrize("W,H,dmin,dmax,opt", [
+    (200, 120, 0, 256, {}),                       # 128 disparities per slot, both chunks full
+    (170, 90, 0, 70, {}),                         # 64 per slot, second chunk partly empty
+    (150, 130, 3, 133, {}),                       # 130 disparities: 128-wide slots, second chunk nearly empty
+    (97, 75, -4, 60, dict(cross_L1=20, cross_L2=9)),
+    (64, 33, 0, 16, dict(cross_L1=5, cross_L2=2)),   # segments shorter than a block
+    (40, 300, 0, 40, dict(cross_L1=40)),          # long columns, arms beyond the default
+])
+def test_fused_aggregation_pairs(pkg, orc, synth, monkeypatch, W, H, dmin, dmax, opt):
+    """ADC_AGG_FUSE=2 runs the dividing pass and the same-axis pass behind it as one launch whatever the frame size
+    (by default only large frames do); every tap must still be the oracle's bits, with and without the taps'
+    separate cost kernel, and equal to the unfused pipeline's."""
+    monkeypatch.setenv("ADC_AGG_FUSE", "2")
+    L, R, _ = synth.pair(180, max(W, 16), max(H, 16), max(dmax - dmin, 8))
+    L, R = np.ascontiguousarray(L[:H, :W]), np.ascontiguousarray(R[:H, :W])
+    got = check_against_oracle(pkg, orc, L, R, min_disparity=dmin, max_disparity=dmax, **opt)
+    h = pkg.ADCensusStereo(0)
+    assert h.Initialize(W, H, pkg.ADCensusOption(min_disparity=dmin, max_disparity=dmax, **opt)), h.last_error()
+    disp = h.match(L, R)              # no taps: the first pass computes the costs itself, other ping-pong order
+    vol = h.get_buffer("cost_scan")
+    aux = h.get_buffer("cost_scan_aux")
+    h.close()
+    assert same(disp, got["disp_final"]) and same(vol, got["cost_scan"]) and same(aux, got["cost_scan_aux"])
