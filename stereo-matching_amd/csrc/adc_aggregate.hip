@@ -520,11 +520,20 @@ k_agg_pair(const float *__restrict__ src, float *__restrict__ dst, const uint32_
 //   bits  0..6   first slot of the run, as a distance below p          (0 .. 127)
 //   bits  7..13  head length      bits 14..21  middle length      bits 22..28  tail length
 //   bit   29     the head belongs to the second window      bit 30   the tail belongs to the second window
-// A lone last position (odd line length) has an empty second window: everything is head of the first.
-// {descriptor, (float)count of p, (float)count of p+1, 0} per pair, pairs of a line contiguous.
+//   bit   31     the pair has a second position (only the last pair of a line of odd length has none)
+// A lone last position has an empty second window: everything is head of the first.
+// {descriptor, (float)count of p, (float)count of p+1, 0} per pair; the pairs of a line are contiguous and every
+// line is padded with pair_desc_pad() all-zero records in front and behind (zeroed when the handle is initialised,
+// never written): a zero descriptor is "no position here", so the fused kernel needs no range checks of its own
+// for the blocks it processes before the start and behind the end of a line.
+// (the kernel starts cap + B positions, i.e. up to cap + B pairs' worth of blocks, before a line and its look-ahead
+// ends up to cap/2 + 3B/2 pairs behind it)
+int pair_desc_pad(int max_arm) { return ((max_arm + 1) & ~1) + 2 * PAIR_B + 2; }
+size_t pair_desc_count(int lines, int len, int max_arm) { return (size_t)lines * ((len + 1) / 2 + 2 * pair_desc_pad(max_arm)); }
+
 __global__ void __launch_bounds__(256)
 k_pair_desc(const uint32_t *__restrict__ arms, const uint32_t *__restrict__ cnt_for_h, const uint32_t *__restrict__ cnt_for_v,
-            uint4 *__restrict__ desc_h, uint4 *__restrict__ desc_v, int W, int H) {
+            uint4 *__restrict__ desc_h, uint4 *__restrict__ desc_v, int W, int H, int pad) {
     const int vertical = blockIdx.z;
     const int LEN = vertical ? H : W, lines = vertical ? W : H;
     const int npairs = (LEN + 1) >> 1;
@@ -550,17 +559,18 @@ k_pair_desc(const uint32_t *__restrict__ arms, const uint32_t *__restrict__ cnt_
     const bool t0 = e0 > e1, t1 = e1 > e0;
     const int tn = t0 ? e0 - max(b0, e1 + 1) + 1 : (t1 ? e1 - max(b1, e0 + 1) + 1 : 0);
     const uint32_t d = (uint32_t)(-min(b0, b1)) | (uint32_t)hn << 7 | (uint32_t)mn << 14 | (uint32_t)tn << 22 |
-                       (h1 ? 1u << 29 : 0u) | (t1 ? 1u << 30 : 0u);
+                       (h1 ? 1u << 29 : 0u) | (t1 ? 1u << 30 : 0u) | (two ? 1u << 31 : 0u);
     const uint32_t *cnt = vertical ? cnt_for_v : cnt_for_h;
     const uint4 rec = make_uint4(d, __float_as_uint((float)cnt[i0]), __float_as_uint((float)cnt[i1]), 0u);
-    (vertical ? desc_v : desc_h)[(size_t)line * npairs + pair] = rec;
+    (vertical ? desc_v : desc_h)[(size_t)line * (npairs + 2 * pad) + pad + pair] = rec;
 }
 
 // cnt_for_h: the counts horizontal dividing passes divide by (the vertical-first order's), cnt_for_v: the others
 void launch_pair_descriptors(const uint32_t *arms, const uint32_t *cnt_for_h, const uint32_t *cnt_for_v, uint4 *desc_h,
-                             uint4 *desc_v, const Geom &g, hipStream_t s) {
+                             uint4 *desc_v, const Geom &g, int max_arm, hipStream_t s) {
     const size_t n = std::max((size_t)g.H * ((g.W + 1) / 2), (size_t)g.W * ((g.H + 1) / 2));
-    k_pair_desc<<<dim3((unsigned)((n + 255) / 256), 1, 2), dim3(256), 0, s>>>(arms, cnt_for_h, cnt_for_v, desc_h, desc_v, g.W, g.H);
+    k_pair_desc<<<dim3((unsigned)((n + 255) / 256), 1, 2), dim3(256), 0, s>>>(arms, cnt_for_h, cnt_for_v, desc_h, desc_v, g.W, g.H,
+                                                                              pair_desc_pad(max_arm));
 }
 
 // n consecutive slots from byte-free float pointer q, n known to be small most of the time (heads and tails)
@@ -614,10 +624,10 @@ __device__ __forceinline__ void desc_windows(typename VecT<VEC>::T &acc0, typena
 template <int VEC, bool FULLD>
 __global__ void __launch_bounds__(AGG_WAVES * 64)
 k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 *__restrict__ desc,
-            int W, int H, int Dp, int vertical, int seglen, int cap, int R) {
-    // cap: the arm cap rounded up to an even number. Segments start at multiples of B, so every pair of positions
-    // starts at an even position of the line and at an even ring slot (R is even): a pair never straddles the
-    // end of a ring or the start of a valid range, and only the last pair of a line of odd length is a lone one.
+            int W, int H, int Dp, int vertical, int cap, int R, int dpad) {
+    // One workgroup = one whole line x one chunk of disparities. cap: the arm cap rounded up to an even number.
+    // Blocks start at multiples of B, so every pair of positions starts at an even position of the line and at
+    // an even ring slot (R is even): a pair never straddles the end of a ring.
     typedef typename VecT<VEC>::T vec_t;
     typedef volatile vec_t __attribute__((address_space(3))) *lds_vec_ptr;
     constexpr int SLOT = 64 * VEC;
@@ -629,11 +639,6 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
     const int kc = blockIdx.x * SLOT;
     const int line = blockIdx.y;
     const int LEN = vertical ? H : W;
-    const int s0 = blockIdx.z * seglen;
-    if (s0 >= LEN) return;
-    const int s1 = min(LEN, s0 + seglen);
-    const int lo_a = max(0, s0 - cap), hi_a = min(LEN, s1 + cap);     // stage-1 positions this segment needs (lo_a even)
-    const int lo_s = max(0, lo_a - cap), hi_s = min(LEN, hi_a + cap); // input positions those need
     const int mstride = vertical ? W * Dp : Dp;
     const size_t lbase = (vertical ? (size_t)line * Dp : (size_t)line * W * Dp) + (size_t)kc;
     bool fok[VEC];
@@ -642,18 +647,18 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
     const float *fsrc = src + lbase + lane;
     const bool kok = FULLD || kc + lane * VEC < Dp;
     const float *rl1 = ring + lane * VEC, *rl2 = ring2 + lane * VEC;
-    const uint4 *dline = desc + (size_t)line * ((LEN + 1) >> 1);       // this line's pair descriptors
 
-    // Iteration j = -nlead, ..., 0, 1, ...: stage 1 on positions pa .. pa+B-1, pa = s0 + cap + B*(j+1); stage 2
-    // (j >= 0) on o0 .. o0+B-1, o0 = s0 + B*j; fills of the inputs stage 1 of iteration j+1 adds to its windows.
+    // Iteration j = -nlead, ..., 0, 1, ...: stage 1 on positions pa .. pa+B-1, pa = cap + B*(j+1); stage 2 on
+    // o0 .. o0+B-1, o0 = B*j; fills of the inputs stage 1 of iteration j+1 adds to its windows. Positions before
+    // the line (the lead-in: stage 1 has to run cap + B ahead) and behind it have zero descriptors and are skipped.
     const int nlead = (2 * cap + B - 1) / B + 1;
-    int pa = s0 + cap + B * (1 - nlead);          // <= s0 - cap: the first stage-1 block starts at or before lo_a
+    int pa = cap + B * (1 - nlead);               // <= -cap
     // ring 1: slot 0 <-> position pa - cap of the first iteration; ring 2: slot 0 <-> the first pa
     {
         const int base1 = pa - cap;
         for (int i = wave; i < 2 * cap + B; i += AGG_WAVES) {
             const int x = base1 + i;
-            if (x >= lo_s && x < hi_s) {
+            if (x >= 0 && x < LEN) {
                 const float *g = fsrc + (size_t)x * mstride;
 #pragma unroll
                 for (int h = 0; h < VEC; h++)
@@ -668,24 +673,21 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
     int qf = 2 * cap + B + 2 * wave;               // ring-1 slot of this wave's first fill of the iteration
     if (qf >= R) qf -= R;
     int qw = 2 * wave;                             // ring-2 slot of this wave's first stage-1 position
-    int q2 = (s0 - pa) % R + 2 * wave;             // ring-2 slot of this wave's first stage-2 position (from j = 0 on)
+    int q2 = R - cap - B + 2 * wave;               // ring-2 slot of this wave's first stage-2 position, -B*nlead + 2*wave
     if (q2 >= R) q2 -= R;
     const ptrdiff_t blk_m = (ptrdiff_t)B * mstride;
-    const float *fill_p = fsrc + (ptrdiff_t)(pa + B + cap + 2 * wave) * mstride;   // (only dereferenced inside [lo_s, hi_s))
-    float *out_p = dst + lbase + lane * VEC + (size_t)(s0 + 2 * wave) * mstride;
-    // pair indices of this wave's stage-1 / stage-2 pair (descriptors are fetched by scalar loads one iteration
-    // ahead of their use; only indices inside the line are dereferenced)
-    int i1 = (pa >> 1) + wave, i2 = (s0 >> 1) + wave;
-    uint4 d1c = make_uint4(0u, 0u, 0u, 0u);
-    uint32_t d2c = 0u;
-    if (pa + 2 * wave >= lo_a && pa + 2 * wave < hi_a) d1c = dline[i1];
-    if (s0 + 2 * wave < s1) d2c = dline[i2].x;
+    int f = pa + B + cap + 2 * wave;               // first of the two positions this wave fills next (> 0)
+    const float *fill_p = fsrc + (ptrdiff_t)f * mstride;
+    float *out_p = dst + lbase + lane * VEC + (ptrdiff_t)(2 * wave - B * nlead) * mstride;   // (stored to inside the line only)
+    // this wave's pair descriptors, fetched (scalar loads) one iteration ahead of their use
+    const uint4 *d1p = desc + (size_t)line * (((LEN + 1) >> 1) + 2 * dpad) + dpad + ((pa >> 1) + wave);
+    const uint4 *d2p = desc + (size_t)line * (((LEN + 1) >> 1) + 2 * dpad) + dpad + (wave - (B * nlead) / 2);
+    uint4 d1c = d1p[0];
+    uint32_t d2c = d2p[0].x;
 
-    for (int o0 = s0 - B * nlead; o0 < s1; o0 += B, pa += B) {
-        const bool run2 = o0 >= s0;
-        // (a) fills for stage 1 of the next iteration (the pair's two positions; qf is even, so qf + 1 < R)
-        const int f = pa + B + cap + 2 * wave;
-        const int nfill = f + 1 < hi_s ? 2 : (f < hi_s ? 1 : 0);
+    for (int o0 = -B * nlead; o0 < LEN; o0 += B) {
+        // (a) fills for stage 1 of the next iteration: the pair's two positions (qf is even: qf + 1 < R)
+        const int nfill = min(max(LEN - f, 0), 2);
         __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int t = 0; t < 2; t++) {
@@ -701,45 +703,30 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
             }
         }
         __builtin_amdgcn_s_setprio(0);
-        // next iteration's descriptors
-        uint4 d1n = make_uint4(0u, 0u, 0u, 0u);
-        uint32_t d2n = d2c;
-        {
-            const int pn = pa + B + 2 * wave;
-            if (pn >= lo_a && pn < hi_a) d1n = dline[i1 + B / 2];
-            if (run2 && o0 + B + 2 * wave < s1) d2n = dline[i2 + B / 2].x;
-        }
+        const uint4 d1n = d1p[B / 2];
+        const uint32_t d2n = d2p[B / 2].x;
         // (b) stage 1: A of positions p, p + 1 into ring 2
-        {
-            const int p = pa + 2 * wave;
-            if (p >= lo_a && p < hi_a) {
-                vec_t acc0, acc1;
-                desc_windows<VEC>(acc0, acc1, rl1, R, q1, d1c.x);
-                acc0 = div_by_count<VEC>(acc0, __uint_as_float(d1c.y));
-                *(lds_vec_ptr)(uintptr_t)(rl2 + qw * SLOT) = acc0;
-                if (p + 1 < hi_a) {
-                    acc1 = div_by_count<VEC>(acc1, __uint_as_float(d1c.z));
-                    *(lds_vec_ptr)(uintptr_t)(rl2 + (qw + 1) * SLOT) = acc1;
-                }
+        if (d1c.x) {
+            vec_t acc0, acc1;
+            desc_windows<VEC>(acc0, acc1, rl1, R, q1, d1c.x);
+            acc0 = div_by_count<VEC>(acc0, __uint_as_float(d1c.y));
+            *(lds_vec_ptr)(uintptr_t)(rl2 + qw * SLOT) = acc0;
+            if (d1c.x >> 31) {
+                acc1 = div_by_count<VEC>(acc1, __uint_as_float(d1c.z));
+                *(lds_vec_ptr)(uintptr_t)(rl2 + (qw + 1) * SLOT) = acc1;
             }
         }
         // (c) stage 2: outputs o, o + 1 from ring 2 (written before the previous barrier)
         int nstore = 0;
-        if (run2) {
-            const int o = o0 + 2 * wave;
-            if (o < s1) {
-                const bool two = o + 1 < s1;
-                vec_t acc0, acc1;
-                desc_windows<VEC>(acc0, acc1, rl2, R, q2, d2c);
-                if (kok) {
-                    *reinterpret_cast<vec_t *>(out_p) = acc0;
-                    if (two) *reinterpret_cast<vec_t *>(out_p + mstride) = acc1;
-                }
-                nstore = two ? 2 : 1;
+        if (d2c) {
+            vec_t acc0, acc1;
+            desc_windows<VEC>(acc0, acc1, rl2, R, q2, d2c);
+            const bool two = d2c >> 31;
+            if (kok) {
+                *reinterpret_cast<vec_t *>(out_p) = acc0;
+                if (two) *reinterpret_cast<vec_t *>(out_p + mstride) = acc1;
             }
-            q2 += B; if (q2 >= R) q2 -= R;
-            out_p += blk_m;
-            i2 += B / 2;
+            nstore = two ? 2 : 1;
         }
         d1c = d1n;
         d2c = d2n;
@@ -752,8 +739,12 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
         q1 += B; if (q1 >= R) q1 -= R;
         qf += B; if (qf >= R) qf -= R;
         qw += B; if (qw >= R) qw -= R;
+        q2 += B; if (q2 >= R) q2 -= R;
+        f += B;
         fill_p += blk_m;
-        i1 += B / 2;
+        out_p += blk_m;
+        d1p += B / 2;
+        d2p += B / 2;
     }
 }
 
@@ -905,14 +896,12 @@ void launch_aggregate_fused_pair(const float *src, float *dst, const uint4 *desc
     const int SLOT = 64 * vec;
     const int chunks = (g.Dp + SLOT - 1) / SLOT;
     const int lines = vertical ? g.W : g.H;
-    const int LEN = vertical ? g.H : g.W;
     const int cap = (max_arm + 1) & ~1;                      // even (see the kernel)
     const int R = 2 * cap + 2 * PAIR_B;
     const size_t lds = (size_t)2 * R * SLOT * sizeof(float);
-    int seglen = ((LEN + PAIR_B - 1) / PAIR_B) * PAIR_B;     // whole lines
-    dim3 grid(chunks, lines, (LEN + seglen - 1) / seglen), block(AGG_WAVES * 64);
+    dim3 grid(chunks, lines), block(AGG_WAVES * 64);
     const bool fulld = g.Dp % SLOT == 0;
-#define ADC_FUSED_GO(V_, F_) k_agg_fused<V_, F_><<<grid, block, lds, s>>>(src, dst, desc, g.W, g.H, g.Dp, vertical, seglen, cap, R)
+#define ADC_FUSED_GO(V_, F_) k_agg_fused<V_, F_><<<grid, block, lds, s>>>(src, dst, desc, g.W, g.H, g.Dp, vertical, cap, R, pair_desc_pad(max_arm))
     if (vec == 2) { if (fulld) ADC_FUSED_GO(2, true); else ADC_FUSED_GO(2, false); }
     else { if (fulld) ADC_FUSED_GO(1, true); else ADC_FUSED_GO(1, false); }
 #undef ADC_FUSED_GO

@@ -225,7 +225,9 @@ int do_initialize(adc_handle *h, int32_t W, int32_t H, const adc_option *opt, hi
         A(h->pl.rec_hf, nrec); A(h->pl.rec_hb, nrec); A(h->pl.rec_v, nrec);
         A(h->pl.rec_rows, (size_t)3 * g.H * scan_row_dwords(g));
     }
-    A(h->pl.pair_h, (size_t)H * ((W + 1) / 2)); A(h->pl.pair_v, (size_t)W * ((H + 1) / 2));
+    const int arm_cap = opt->cross_L1 < 0 ? 0 : (opt->cross_L1 < 255 ? opt->cross_L1 : 255);
+    const size_t n_pair_h = pair_desc_count(H, W, arm_cap), n_pair_v = pair_desc_count(W, H, arm_cap);
+    A(h->pl.pair_h, n_pair_h); A(h->pl.pair_v, n_pair_v);
     A(h->vol_a, nvol); A(h->vol_b, nvol);
     A(h->lut_ad, 768); A(h->lut_cen, 68);
     A(h->disp_a, npx); A(h->disp_b, npx); A(h->disp_r, npx); A(h->disp_final, npx);
@@ -253,6 +255,9 @@ int do_initialize(adc_handle *h, int32_t W, int32_t H, const adc_option *opt, hi
     HIPCHK(h, hipMemsetAsync(h->vol_b, 0, nvol * sizeof(float), s0));
     HIPCHK(h, hipMemsetAsync(h->tile_stamp, 0, (size_t)vote_tiles_w(W) * vote_tiles_h(H) * sizeof(uint32_t), s0));
     h->vote_stamp = 16;
+    // the padding records in front of and behind every line of the pair descriptors stay zero for good
+    HIPCHK(h, hipMemsetAsync(h->pl.pair_h, 0, n_pair_h * sizeof(uint4), s0));
+    HIPCHK(h, hipMemsetAsync(h->pl.pair_v, 0, n_pair_v * sizeof(uint4), s0));
 
     // exp tables of the initial cost (ADC/cost_computor.cu:186,200-203): entry = expf of the float
     // argument, taken as the correctly rounded (float)exp((double)arg).
@@ -354,7 +359,7 @@ int enqueue_match(adc_handle *h, const uint8_t *d_l, const uint8_t *d_r, float *
     const int cap = max_arm_of(o);
     const bool fuse_pairs = h->agg_variant == 0 && aggregate_pair_fusion_supported(g, cap);
     // horizontal dividing passes divide by the vertical-first counts, vertical ones by the horizontal-first counts
-    if (fuse_pairs) launch_pair_descriptors(pl.arms, pl.cnt_v32, pl.cnt_h32, pl.pair_h, pl.pair_v, g, s);
+    if (fuse_pairs) launch_pair_descriptors(pl.arms, pl.cnt_v32, pl.cnt_h32, pl.pair_h, pl.pair_v, g, cap, s);
 
     // The initial cost volume is computed inside the first aggregation pass when that is possible; it is
     // materialised (ComputeCostCuda as a kernel of its own) when its tap is wanted or the pass cannot hold it.

@@ -71,8 +71,9 @@ void launch_aggregate_first_pass_with_cost(const Planes &p, const float *lut_ad,
 // as one launch, the intermediate volume staying in LDS: only when aggregate_pair_fusion_supported().
 bool aggregate_pair_fusion_supported(const Geom &g, int max_arm);
 // per frame: the window geometry of every pair of neighbouring positions, per axis (Planes::pair_h / pair_v)
+size_t pair_desc_count(int lines, int len, int max_arm);   // records of one axis's descriptor plane (rows are padded)
 void launch_pair_descriptors(const uint32_t *arms, const uint32_t *cnt_for_h, const uint32_t *cnt_for_v, uint4 *desc_h,
-                             uint4 *desc_v, const Geom &g, hipStream_t s);
+                             uint4 *desc_v, const Geom &g, int max_arm, hipStream_t s);
 void launch_aggregate_fused_pair(const float *src, float *dst, const uint4 *desc, const Geom &g, int vertical, int max_arm,
                                  hipStream_t s);
 
