@@ -679,11 +679,21 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
     int f = pa + B + cap + 2 * wave;               // first of the two positions this wave fills next (> 0)
     const float *fill_p = fsrc + (ptrdiff_t)f * mstride;
     float *out_p = dst + lbase + lane * VEC + (ptrdiff_t)(2 * wave - B * nlead) * mstride;   // (stored to inside the line only)
-    // this wave's pair descriptors, fetched (scalar loads) one iteration ahead of their use
+    // This wave's pair descriptors are fetched one iteration ahead of their use -- by vector loads of a uniform
+    // address, made uniform registers again with v_readfirstlane once they are needed. Scalar loads would be the
+    // natural form, but they share the LDS's wait counter and return out of order, so the first wait for a ring
+    // read would also sit out the whole scalar load; vector loads count in order with the fills and the stores.
     const uint4 *d1p = desc + (size_t)line * (((LEN + 1) >> 1) + 2 * dpad) + dpad + ((pa >> 1) + wave);
     const uint4 *d2p = desc + (size_t)line * (((LEN + 1) >> 1) + 2 * dpad) + dpad + (wave - (B * nlead) / 2);
-    uint4 d1c = d1p[0];
-    uint32_t d2c = d2p[0].x;
+    // (a zero the compiler cannot see through keeps the address a vector value, hence the loads vector loads whose
+    // completion the compiler tracks itself)
+    int vzero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+    auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    uint4 d1v = d1p[vzero];
+    uint32_t d2v = d2p[vzero].x;
+    uint4 d1c = make_uint4(uni(d1v.x), uni(d1v.y), uni(d1v.z), 0u);
+    uint32_t d2c = uni(d2v);
 
     for (int o0 = -B * nlead; o0 < LEN; o0 += B) {
         // (a) fills for stage 1 of the next iteration: the pair's two positions (qf is even: qf + 1 < R)
@@ -703,8 +713,8 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
             }
         }
         __builtin_amdgcn_s_setprio(0);
-        const uint4 d1n = d1p[B / 2];
-        const uint32_t d2n = d2p[B / 2].x;
+        d1v = d1p[B / 2 + vzero];
+        d2v = d2p[B / 2 + vzero].x;
         // (b) stage 1: A of positions p, p + 1 into ring 2
         if (d1c.x) {
             vec_t acc0, acc1;
@@ -716,6 +726,10 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
                 *(lds_vec_ptr)(uintptr_t)(rl2 + (qw + 1) * SLOT) = acc1;
             }
         }
+        // the next iteration's descriptors have long landed by now (nothing younger than their loads is in flight
+        // here, so the wait the compiler puts in front of these costs nothing; behind the stores it would wait for them)
+        const uint4 d1n = make_uint4(uni(d1v.x), uni(d1v.y), uni(d1v.z), 0u);
+        const uint32_t d2n = uni(d2v);
         // (c) stage 2: outputs o, o + 1 from ring 2 (written before the previous barrier)
         int nstore = 0;
         if (d2c) {
@@ -728,12 +742,12 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
             }
             nstore = two ? 2 : 1;
         }
+        // (d) the fills must have landed before the next iteration reads them, and the descriptors have to be
+        //     there: in the steady state both are older than exactly this iteration's two stores
+        if (nstore == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         d1c = d1n;
         d2c = d2n;
-        // (d) the fills must have landed before the next iteration reads them: in the steady state they are
-        //     older than exactly this iteration's two stores
-        if (nfill == 2 && nstore == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else if (nfill) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         q1 += B; if (q1 >= R) q1 -= R;
