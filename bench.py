@@ -14,13 +14,13 @@ independent, there is no collective in the data path; torch.distributed is only 
 barrier and the max-over-ranks of the timed region. Rank 0 prints one JSON line.
 
 Extra objects on that line:
-  roofline         -- the dominant kernel (one launch of the cross-aggregation kernel). Algorithmic bytes per
-                      launch follow the stage-boundary model: an aggregation ITERATION reads and writes the
-                      volume once (8 B per pixel*disparity); this build runs an iteration as two launches, so
-                      one launch carries 4 B per pixel*disparity. The per-launch duration is the mean over the
-                      eight launches of a match, each timed on its own with HIP events on the launch stream.
-                      `per_pass` repeats the figure with the 8 B a single pass actually has to move.
+  roofline         -- the dominant kernel (the roofline_kernels entry with the largest share of a match). Algorithmic
+                      bytes per launch follow the stage-boundary model: an aggregation ITERATION reads and writes
+                      the volume once (8 B per pixel*disparity), i.e. 4 B per pass; a launch that runs two passes
+                      (the fused aggregation kernel) carries 8 B, one that runs one pass 4 B. Launch durations are
+                      measured per launch with HIP events on the launch stream.
   roofline_kernels -- the same accounting for every volume kernel of a match, launch by launch.
+  aggregation_stage-- all aggregation launches together against the model's 32 B (+4 B for the cost volume).
   t_match          -- the host-pointer boundary (adc_match) on pinned host images: wall time per frame with the
                       upload of the two images and the download of the map inside, and those two separately.
   cpu_baseline     -- the CPU oracle (a port of the reference path; the reference has no CPU-only path of its
@@ -168,7 +168,8 @@ def main():
                 "model": what, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS}
 
     cost_fused = kern_acc["cost"] < 0.05 * kern_acc["aggr0"]
-    aggr_all = ["aggr%d" % i for i in range(8)]
+    # large frames run the passes 1+2, 3+4, 5+6 as one launch each (ids 1, 3, 5; ids 2, 4, 6 then take no time)
+    pairs_fused = all(kern_acc["aggr%d" % i] < 0.05 * kern_acc["aggr%d" % (i - 1)] for i in (2, 4, 6))
     per_kernel = []
     if cost_fused:
         per_kernel.append(entry("k_agg_pair<COST> (initial cost computed inside the first aggregation launch)", ["aggr0"], 8.0,
@@ -176,29 +177,50 @@ def main():
     else:
         per_kernel.append(entry("k_cost_init", ["cost"], 4.0, "cost-volume write 4 B"))
         per_kernel.append(entry("aggregation launch 0", ["aggr0"], 4.0, "half an aggregation iteration"))
-    per_kernel.append(entry("k_agg_pair (aggregation launches 1..7)", aggr_all[1:], 4.0,
-                            "half an aggregation iteration: the model charges 8 B per iteration, an iteration is two launches"))
+    if pairs_fused:
+        per_kernel.append(entry("k_agg_fused (passes 1+2, 3+4, 5+6: a dividing pass and the same-axis pass behind it per launch)",
+                                ["aggr1", "aggr3", "aggr5"], 8.0,
+                                "two half iterations: the model charges 8 B per iteration = 4 B per pass; the volume between "
+                                "the two passes stays in LDS, so the launch really moves 8 B"))
+        per_kernel.append(entry("k_agg_pair (last aggregation pass)", ["aggr7"], 4.0, "half an aggregation iteration"))
+        agg_names = ["aggr0", "aggr1", "aggr3", "aggr5", "aggr7"]
+    else:
+        per_kernel.append(entry("k_agg_pair (aggregation launches 1..7)", ["aggr%d" % i for i in range(1, 8)], 4.0,
+                                "half an aggregation iteration: the model charges 8 B per iteration, an iteration is two launches"))
+        agg_names = ["aggr%d" % i for i in range(8)]
     per_kernel.append(entry("scanline pass, horizontal (launches 0,1)", ["scan0", "scan1"], 8.0, "volume read 4 B + write 4 B"))
     per_kernel.append(entry("scanline pass, vertical (launches 2,3; the last also writes the left WTA map)", ["scan2", "scan3"], 8.0,
                             "volume read 4 B + write 4 B"))
     per_kernel.append(entry("k_wta_right", ["wta_right"], 4.0, "volume read 4 B"))
+    aggr_stage = {"launches": len(agg_names), "ms": float(sum(kern_acc[n] for n in agg_names)),
+                  "algorithmic_bytes": (36.0 if cost_fused else 32.0) * vol}
+    aggr_stage["achieved"] = aggr_stage["algorithmic_bytes"] / (aggr_stage["ms"] * 1e-3) / 1e9
+    aggr_stage["frac"] = aggr_stage["achieved"] / HBM_PEAK_GBS
 
     # HBM bytes per aggregation launch as measured by the PMC passes under profiles/ -- only if they were taken
     # on exactly these kernel sources and this workload
-    traffic, traffic_src = None, None
+    traffic_json = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         if tj["workload"] == {"width": W, "height": H, "disparities": D} and tj.get("source_stamp") == kernel_source_stamp():
-            traffic = tj["aggregation_pass"]["hbm_bytes_per_launch"]
-            traffic_src = tj.get("profiles")
+            traffic_json = tj
     except (OSError, KeyError, ValueError):
         pass
 
     if rank == 0:
         ms_per_frame = elapsed / args.steps * 1e3
-        agg = entry("k_agg_pair (one launch of the cross-aggregation kernel; 8 per match)", aggr_all, 4.0,
-                    "8 B per pixel*disparity per aggregation iteration, two launches per iteration")
-        agg_pass = 8.0 * vol / (agg["launch_ms"] * 1e-3) / 1e9
+        # the dominant kernel: the entry with the largest share of the match
+        dom = max(per_kernel, key=lambda e: e["launches"] * e["launch_ms"])
+        traffic, traffic_src = None, None
+        if traffic_json:
+            import re
+            pat = (r"k_agg_fused" if "k_agg_fused" in dom["kernel"] else
+                   r"k_agg_pair<\d, (true|false), false," if "k_agg_pair" in dom["kernel"] else
+                   r"k_scanline" if "scanline" in dom["kernel"] else r"k_wta_right")
+            hits = [v["hbm_bytes_per_launch"] for name, v in traffic_json.get("per_kernel", {}).items() if re.search(pat, name)]
+            if hits:
+                traffic = float(np.mean(hits))
+                traffic_src = traffic_json.get("profiles")
         out = {
             "metric": "Mpix*disp/s",
             "value": batch.throughput(world, args.steps, W, H, D, elapsed),
@@ -220,12 +242,11 @@ def main():
             "stage_ms": {k: round(v, 4) for k, v in stage_acc.items()},
             "kernel_ms": {k: round(v, 4) for k, v in kern_acc.items()},
             "valid_fraction": valid_fraction,
-            "roofline": {"bound": "hbm", "kernel": agg["kernel"], "achieved": agg["achieved"], "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": agg["frac"], "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": agg["algorithmic_bytes_per_launch"], "launch_ms": agg["launch_ms"],
-                         "per_pass": {"algorithmic_bytes_per_launch": 8.0 * vol, "achieved": agg_pass,
-                                      "frac": agg_pass / HBM_PEAK_GBS,
-                                      "note": "what one pass has to move on its own: read 4 B + write 4 B"}},
+            "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": dom["frac"], "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "launch_ms": dom["launch_ms"],
+                         "launches_per_match": dom["launches"], "model": dom["model"]},
+            "aggregation_stage": aggr_stage,
             "roofline_kernels": per_kernel,
             "t_match": t_match,
         }
