@@ -624,16 +624,16 @@ __device__ __forceinline__ void desc_windows(typename VecT<VEC>::T &acc0, typena
 template <int VEC, bool FULLD>
 __global__ void __launch_bounds__(AGG_WAVES * 64)
 k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 *__restrict__ desc,
-            int W, int H, int Dp, int vertical, int cap, int R, int dpad) {
+            int W, int H, int Dp, int vertical, int cap, int R1, int R2, int dpad) {
     // One workgroup = one whole line x one chunk of disparities. cap: the arm cap rounded up to an even number.
     // Blocks start at multiples of B, so every pair of positions starts at an even position of the line and at
-    // an even ring slot (R is even): a pair never straddles the end of a ring.
+    // an even ring slot (R1, R2 are even): a pair never straddles the end of a ring.
     typedef typename VecT<VEC>::T vec_t;
     typedef volatile vec_t __attribute__((address_space(3))) *lds_vec_ptr;
     constexpr int SLOT = 64 * VEC;
     constexpr int B = PAIR_B;
-    extern __shared__ __align__(16) float ring[];   // ring 1 (src): R x SLOT, then ring 2 (A): R x SLOT
-    float *const ring2 = ring + (size_t)R * SLOT;
+    extern __shared__ __align__(16) float ring[];   // ring 1 (src): R1 x SLOT, then ring 2 (A): R2 x SLOT
+    float *const ring2 = ring + (size_t)R1 * SLOT;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kc = blockIdx.x * SLOT;
@@ -649,14 +649,16 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
     const float *rl1 = ring + lane * VEC, *rl2 = ring2 + lane * VEC;
 
     // Iteration j = -nlead, ..., 0, 1, ...: stage 1 on positions pa .. pa+B-1, pa = cap + B*(j+1); stage 2 on
-    // o0 .. o0+B-1, o0 = B*j; fills of the inputs stage 1 of iteration j+1 adds to its windows. Positions before
-    // the line (the lead-in: stage 1 has to run cap + B ahead) and behind it have zero descriptors and are skipped.
+    // o0 .. o0+B-1, o0 = B*j; fills of the inputs stage 1 of iteration j+2 adds to its windows (two blocks ahead:
+    // one workgroup per CU has to keep that much of HBM's latency covered by itself). Positions before the line
+    // (the lead-in: stage 1 has to run cap + B ahead) and behind it have zero descriptors and are skipped.
     const int nlead = (2 * cap + B - 1) / B + 1;
     int pa = cap + B * (1 - nlead);               // <= -cap
-    // ring 1: slot 0 <-> position pa - cap of the first iteration; ring 2: slot 0 <-> the first pa
+    // ring 1 (R1 = 2*cap + 3*B slots): slot 0 <-> position pa - cap of the first iteration;
+    // ring 2 (R2 = 2*cap + 2*B slots): slot 0 <-> the first pa
     {
         const int base1 = pa - cap;
-        for (int i = wave; i < 2 * cap + B; i += AGG_WAVES) {
+        for (int i = wave; i < 2 * cap + 2 * B; i += AGG_WAVES) {
             const int x = base1 + i;
             if (x >= 0 && x < LEN) {
                 const float *g = fsrc + (size_t)x * mstride;
@@ -670,55 +672,81 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
     __builtin_amdgcn_s_barrier();
 
     int q1 = cap + 2 * wave;                       // ring-1 slot of this wave's first stage-1 position
-    int qf = 2 * cap + B + 2 * wave;               // ring-1 slot of this wave's first fill of the iteration
-    if (qf >= R) qf -= R;
+    int qf = 2 * cap + 2 * B + 2 * wave;           // ring-1 slot of this wave's first fill of the iteration (< R1)
     int qw = 2 * wave;                             // ring-2 slot of this wave's first stage-1 position
-    int q2 = R - cap - B + 2 * wave;               // ring-2 slot of this wave's first stage-2 position, -B*nlead + 2*wave
-    if (q2 >= R) q2 -= R;
+    int q2 = R2 - cap - B + 2 * wave;              // ring-2 slot of this wave's first stage-2 position, -B*nlead + 2*wave
+    if (q2 >= R2) q2 -= R2;
     const ptrdiff_t blk_m = (ptrdiff_t)B * mstride;
-    int f = pa + B + cap + 2 * wave;               // first of the two positions this wave fills next (> 0)
-    const float *fill_p = fsrc + (ptrdiff_t)f * mstride;
+    // Fills: this wave's pair of positions f, f + 1 of every iteration. Two (VEC = 2: four) fill instructions are
+    // issued in EVERY iteration, so that the count of operations in flight behind them is fixed: once the pair
+    // lies behind the end of the line the pointer stops at the last pair it reached and the fills re-read that
+    // into slots no window ever reads (fp = the position fill_p points to).
+    const int f0 = pa + 2 * B + cap + 2 * wave;    // > 0
+    int fp = min(f0, LEN - 1);
+    const float *fill_p = fsrc + (ptrdiff_t)fp * mstride;
     float *out_p = dst + lbase + lane * VEC + (ptrdiff_t)(2 * wave - B * nlead) * mstride;   // (stored to inside the line only)
-    // This wave's pair descriptors are fetched one iteration ahead of their use -- by vector loads of a uniform
-    // address, made uniform registers again with v_readfirstlane once they are needed. Scalar loads would be the
-    // natural form, but they share the LDS's wait counter and return out of order, so the first wait for a ring
-    // read would also sit out the whole scalar load; vector loads count in order with the fills and the stores.
-    const uint4 *d1p = desc + (size_t)line * (((LEN + 1) >> 1) + 2 * dpad) + dpad + ((pa >> 1) + wave);
-    const uint4 *d2p = desc + (size_t)line * (((LEN + 1) >> 1) + 2 * dpad) + dpad + (wave - (B * nlead) / 2);
-    // (a zero the compiler cannot see through keeps the address a vector value, hence the loads vector loads whose
-    // completion the compiler tracks itself)
-    int vzero;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+    // This wave's pair descriptors travel like the fills: by LDS-DMA, two iterations ahead of their use, into a
+    // small staging area (two 32-byte slots per wave, used alternately): lanes 0..3 move the stage-1 record, lane 4
+    // the stage-2 descriptor. They are issued in front of the iteration's fills, so the wait for those fills
+    // covers them; the wave then reads its slot (every lane the same address) and makes the values uniform
+    // registers with v_readfirstlane. Scalar loads would be the natural form, but they share the LDS's wait counter
+    // and return out of order: the first wait for a ring read would sit out the whole scalar load. Ordinary vector
+    // loads would make the compiler wait for every fill in flight in front of their first use.
+    const size_t drow = (size_t)line * (((LEN + 1) >> 1) + 2 * dpad) + dpad;
+    const uint4 *d1p = desc + drow + ((pa >> 1) + wave);                  // stage-1 pair of the first iteration
+    const uint4 *d2p = desc + drow + (wave - (B * nlead) / 2);            // stage-2 pair of the first iteration
+    const uint32_t *dsrc = lane < 4 ? reinterpret_cast<const uint32_t *>(d1p) + lane : reinterpret_cast<const uint32_t *>(d2p);
+    float *const stage = ring2 + (size_t)R2 * SLOT + wave * 16;           // this wave's two slots of 8 dwords
+    const uint32_t stage_off = (uint32_t)(uintptr_t)stage;
+    auto desc_dma = [&](int it_ahead, int slot) {   // the descriptors `it_ahead` iterations ahead of dsrc into slot `slot`
+        if (lane < 5)
+            __builtin_amdgcn_global_load_lds(dsrc + (ptrdiff_t)it_ahead * (B / 2) * 4,
+                                             (__attribute__((address_space(3))) void *)(stage + slot * 8), 4, 0, 0);
+    };
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
-    uint4 d1v = d1p[vzero];
-    uint32_t d2v = d2p[vzero].x;
+    // (the slot is read through an address rebuilt from an integer, like the rings: ordering against the DMA is
+    // what the counted waits provide)
+    auto read_slot = [&](int slot, u32x4 &a, uint32_t &b) {
+        typedef const volatile u32x4 __attribute__((address_space(3))) *p4;
+        typedef const volatile uint32_t __attribute__((address_space(3))) *p1;
+        a = *(p4)(uintptr_t)(stage_off + slot * 32);
+        b = *(p1)(uintptr_t)(stage_off + slot * 32 + 16);
+    };
+    desc_dma(0, 0);
+    desc_dma(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    u32x4 d1v;
+    uint32_t d2v;
+    read_slot(0, d1v, d2v);
     uint4 d1c = make_uint4(uni(d1v.x), uni(d1v.y), uni(d1v.z), 0u);
     uint32_t d2c = uni(d2v);
+    int nstore_prev = 0, par = 0;                 // par: the staging slot holding the NEXT iteration's descriptors is 1 - par
 
     for (int o0 = -B * nlead; o0 < LEN; o0 += B) {
-        // (a) fills for stage 1 of the next iteration: the pair's two positions (qf is even: qf + 1 < R)
-        const int nfill = min(max(LEN - f, 0), 2);
-        __builtin_amdgcn_s_setprio(3);
+        // (a) the descriptors of the iteration after the next into the slot this iteration's came from, then the fills
+        desc_dma(2, par);
+        {
+            const float *p1 = fill_p + (fp + 1 < LEN ? (ptrdiff_t)mstride : (ptrdiff_t)0);
+            __builtin_amdgcn_s_setprio(3);
+            if constexpr (FULLD && VEC == 2) {
+                ring_fill(fill_p, ring + qf * SLOT);
+                ring_fill_hi(fill_p, ring + qf * SLOT);
+                ring_fill(p1, ring + (qf + 1) * SLOT);
+                ring_fill_hi(p1, ring + (qf + 1) * SLOT);
+            } else {
 #pragma unroll
-        for (int t = 0; t < 2; t++) {
-            if (t < nfill) {
-                if constexpr (FULLD && VEC == 2) {
-                    ring_fill(fill_p + (ptrdiff_t)t * mstride, ring + (qf + t) * SLOT);
-                    ring_fill_hi(fill_p + (ptrdiff_t)t * mstride, ring + (qf + t) * SLOT);
-                } else {
-#pragma unroll
-                    for (int h = 0; h < VEC; h++)
-                        if (fok[h]) ring_fill(fill_p + (ptrdiff_t)t * mstride + h * 64, ring + (qf + t) * SLOT + h * 64);
+                for (int h = 0; h < VEC; h++) {
+                    if (fok[h]) ring_fill(fill_p + h * 64, ring + qf * SLOT + h * 64);
+                    if (fok[h]) ring_fill(p1 + h * 64, ring + (qf + 1) * SLOT + h * 64);
                 }
             }
+            __builtin_amdgcn_s_setprio(0);
         }
-        __builtin_amdgcn_s_setprio(0);
-        d1v = d1p[B / 2 + vzero];
-        d2v = d2p[B / 2 + vzero].x;
         // (b) stage 1: A of positions p, p + 1 into ring 2
         if (d1c.x) {
             vec_t acc0, acc1;
-            desc_windows<VEC>(acc0, acc1, rl1, R, q1, d1c.x);
+            desc_windows<VEC>(acc0, acc1, rl1, R1, q1, d1c.x);
             acc0 = div_by_count<VEC>(acc0, __uint_as_float(d1c.y));
             *(lds_vec_ptr)(uintptr_t)(rl2 + qw * SLOT) = acc0;
             if (d1c.x >> 31) {
@@ -726,15 +754,11 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
                 *(lds_vec_ptr)(uintptr_t)(rl2 + (qw + 1) * SLOT) = acc1;
             }
         }
-        // the next iteration's descriptors have long landed by now (nothing younger than their loads is in flight
-        // here, so the wait the compiler puts in front of these costs nothing; behind the stores it would wait for them)
-        const uint4 d1n = make_uint4(uni(d1v.x), uni(d1v.y), uni(d1v.z), 0u);
-        const uint32_t d2n = uni(d2v);
         // (c) stage 2: outputs o, o + 1 from ring 2 (written before the previous barrier)
         int nstore = 0;
         if (d2c) {
             vec_t acc0, acc1;
-            desc_windows<VEC>(acc0, acc1, rl2, R, q2, d2c);
+            desc_windows<VEC>(acc0, acc1, rl2, R2, q2, d2c);
             const bool two = d2c >> 31;
             if (kok) {
                 *reinterpret_cast<vec_t *>(out_p) = acc0;
@@ -742,23 +766,30 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
             }
             nstore = two ? 2 : 1;
         }
-        // (d) the fills must have landed before the next iteration reads them, and the descriptors have to be
-        //     there: in the steady state both are older than exactly this iteration's two stores
-        if (nstore == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        d1c = d1n;
-        d2c = d2n;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // (d) the fills of the PREVIOUS iteration must have landed before the next iteration reads them (and with
+        //     them the descriptors issued in front of them, which are the next iteration's). Issued since then, in
+        //     order: that iteration's stores, this one's descriptor DMA, its fills and its stores -- 2 + 1 + 2*VEC + 2
+        //     operations in the steady state, and never fewer than 1 + 2*VEC.
+        if constexpr (FULLD) {
+            if (nstore == 2 && nstore_prev == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 + 2 * VEC) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 + 2 * VEC) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (lane-predicated fills: their number is not fixed)
+        }
+        nstore_prev = nstore;
+        read_slot(1 - par, d1v, d2v);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d1v), "+v"(d2v) : : "memory");
+        d1c = make_uint4(uni(d1v.x), uni(d1v.y), uni(d1v.z), 0u);
+        d2c = uni(d2v);
+        par = 1 - par;
         __builtin_amdgcn_s_barrier();
-        q1 += B; if (q1 >= R) q1 -= R;
-        qf += B; if (qf >= R) qf -= R;
-        qw += B; if (qw >= R) qw -= R;
-        q2 += B; if (q2 >= R) q2 -= R;
-        f += B;
-        fill_p += blk_m;
+        q1 += B; if (q1 >= R1) q1 -= R1;
+        qf += B; if (qf >= R1) qf -= R1;
+        qw += B; if (qw >= R2) qw -= R2;
+        q2 += B; if (q2 >= R2) q2 -= R2;
+        if (fp + B < LEN) { fp += B; fill_p += blk_m; }
         out_p += blk_m;
-        d1p += B / 2;
-        d2p += B / 2;
+        dsrc += (B / 2) * 4;
     }
 }
 
@@ -896,11 +927,11 @@ bool aggregate_pair_fusion_supported(const Geom &g, int max_arm) {
     const char *str = std::getenv("ADC_AGG_FUSE");      // (test hook: 0 never, 2 whatever the frame size)
     const int env = str ? std::atoi(str) : 1;
     const int vec = (g.Dp >= 128 && g.Dp % 2 == 0) ? 2 : 1;
-    const size_t lds = (size_t)2 * (2 * ((max_arm + 1) & ~1) + 2 * PAIR_B) * 64 * vec * 4;
+    const size_t lds = (size_t)(4 * ((max_arm + 1) & ~1) + 5 * PAIR_B) * 64 * vec * 4 + AGG_WAVES * 64;
     const long long chunks = (g.Dp + 64 * vec - 1) / (64 * vec);
     const long long wgs_min = chunks * (g.W < g.H ? g.W : g.H);
     const bool big = wgs_min >= 512 && (long long)g.W * g.H * g.Dp >= (32ll << 20);
-    return env && pair_kernel_ok(g, max_arm) && lds <= 156 * 1024 && (big || env == 2);
+    return env && pair_kernel_ok(g, max_arm) && lds <= 160 * 1024 && (big || env == 2);
 }
 
 // src -> (dividing pass along the axis) -> (plain pass along the same axis) -> dst; desc: that axis's pair descriptors
@@ -911,11 +942,11 @@ void launch_aggregate_fused_pair(const float *src, float *dst, const uint4 *desc
     const int chunks = (g.Dp + SLOT - 1) / SLOT;
     const int lines = vertical ? g.W : g.H;
     const int cap = (max_arm + 1) & ~1;                      // even (see the kernel)
-    const int R = 2 * cap + 2 * PAIR_B;
-    const size_t lds = (size_t)2 * R * SLOT * sizeof(float);
+    const int R1 = 2 * cap + 3 * PAIR_B, R2 = 2 * cap + 2 * PAIR_B;
+    const size_t lds = (size_t)(R1 + R2) * SLOT * sizeof(float) + AGG_WAVES * 64;   // + the descriptor staging slots
     dim3 grid(chunks, lines), block(AGG_WAVES * 64);
     const bool fulld = g.Dp % SLOT == 0;
-#define ADC_FUSED_GO(V_, F_) k_agg_fused<V_, F_><<<grid, block, lds, s>>>(src, dst, desc, g.W, g.H, g.Dp, vertical, cap, R, pair_desc_pad(max_arm))
+#define ADC_FUSED_GO(V_, F_) k_agg_fused<V_, F_><<<grid, block, lds, s>>>(src, dst, desc, g.W, g.H, g.Dp, vertical, cap, R1, R2, pair_desc_pad(max_arm))
     if (vec == 2) { if (fulld) ADC_FUSED_GO(2, true); else ADC_FUSED_GO(2, false); }
     else { if (fulld) ADC_FUSED_GO(1, true); else ADC_FUSED_GO(1, false); }
 #undef ADC_FUSED_GO
