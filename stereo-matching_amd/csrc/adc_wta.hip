@@ -14,7 +14,11 @@
 
 namespace adc {
 
-#define WR_PX 128   // right pixels per workgroup
+#ifndef WR_PX
+#define WR_PX 128   // right pixels per workgroup (128 + 32 staged left pixels per chunk: 1.25x over-read; 256-pixel tiles read
+                    // 1.125x but run 3 % slower: 40 KB of LDS per workgroup leaves fewer loads in flight per CU)
+#endif
+#define WR_NQ (256 / WR_PX)   // threads sharing a right pixel: each scans 1/WR_NQ of a chunk
 #ifndef WR_KC
 #define WR_KC 32    // disparities per staged chunk (32: 128-byte row pieces, 1.25x over-read; 64 was 10 % slower)
 #endif
@@ -32,11 +36,11 @@ template <bool V4>
 __global__ void __launch_bounds__(256)
 k_wta_right(const float *__restrict__ cost, float *__restrict__ disp, int W, int H, int dmin, int D, int Dp) {
     __shared__ float S[(WR_PX + WR_KC) * WR_ST];
-    __shared__ float pm[2][WR_PX];
-    __shared__ int pk[2][WR_PX];
+    __shared__ float pm[WR_NQ][WR_PX];
+    __shared__ int pk[WR_NQ][WR_PX];
     const int y = blockIdx.y, xr0 = blockIdx.x * WR_PX;
     const int t = threadIdx.x;
-    const int l = t & (WR_PX - 1), q = t >> 7;   // scan role: right pixel l, half q of the chunk
+    const int l = t % WR_PX, q = t / WR_PX;      // scan role: right pixel l, part q of the chunk
     constexpr int SRP = 256 / WR_KC;             // rows per staging pass of the scalar path
     const int j = t % WR_KC, r = t / WR_KC;      // staging role: column j, rows r, r+SRP, ...
     const float *row = cost + (size_t)y * W * Dp;
@@ -81,21 +85,26 @@ k_wta_right(const float *__restrict__ cost, float *__restrict__ disp, int W, int
         __syncthreads();
         float mv = ADC_LARGE_F;
         int mk = 0x7fffffff;
-        const int kq = q * (WR_KC / 2);
+        const int kq = q * (WR_KC / WR_NQ);
 #pragma unroll 8
-        for (int kk = 0; kk < WR_KC / 2; kk++) {
+        for (int kk = 0; kk < WR_KC / WR_NQ; kk++) {
             const int k2 = kq + kk;
             const float v = S[(l + k2) * WR_ST + k2];
             if (mv > v) { mv = v; mk = kc + k2; }
         }
-        pm[q][l] = mv;
-        pk[q][l] = mk;
-        __syncthreads();
-        if (q == 0) {
+        if constexpr (WR_NQ == 1) {
+            if (bv > mv) { bv = mv; bk = mk; }
+            __syncthreads();             // the tile is restaged by the next chunk
+        } else {
+            pm[q][l] = mv;
+            pk[q][l] = mk;
+            __syncthreads();
+            if (q == 0) {
 #pragma unroll
-            for (int qq = 0; qq < 2; qq++) {
-                const float v = pm[qq][l];
-                if (bv > v) { bv = v; bk = pk[qq][l]; }
+                for (int qq = 0; qq < WR_NQ; qq++) {
+                    const float v = pm[qq][l];
+                    if (bv > v) { bv = v; bk = pk[qq][l]; }
+                }
             }
         }
     }
