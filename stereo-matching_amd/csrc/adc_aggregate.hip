@@ -52,6 +52,13 @@ __device__ __forceinline__ void ring_fill_hi(const float *gsrc, float *lds_dst) 
     __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void *)lds_dst, 4, 256, 0);
 }
 
+// Four floats per lane: 64 lanes x 16 B = 1 KiB land at dst in one instruction (global_load_lds_dwordx4). Every
+// lane brings its own source address (16-byte aligned), so one instruction can fill neighbouring slots from
+// different image positions.
+__device__ __forceinline__ void ring_fill_x4(const float *gsrc, float *lds_dst) {
+    __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
+}
+
 // One ring read = one ds_read_b32 / ds_read_b64. The access is volatile so that the compiler does not
 // pair two of them into ds_read2(st64)_b64: on gfx950 the paired form runs at half the LDS rate
 // (8 cycles per wave-instruction against 2 for a single ds_read_b64).
@@ -621,6 +628,13 @@ __device__ __forceinline__ void desc_windows(typename VecT<VEC>::T &acc0, typena
     }
 }
 
+#ifdef AGG_STAMP
+// diagnostic build: cycles the waves spend in the parts of an iteration, summed over all waves of all launches
+__device__ unsigned long long g_agg_stamp[8];
+#define STAMP(i) { const unsigned long long t_ = __builtin_readcyclecounter(); st[i] += t_ - tprev; tprev = t_; }
+#else
+#define STAMP(i)
+#endif
 template <int VEC, bool FULLD>
 __global__ void __launch_bounds__(AGG_WAVES * 64)
 k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 *__restrict__ desc,
@@ -684,56 +698,70 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
     const int f0 = pa + 2 * B + cap + 2 * wave;    // > 0
     int fp = min(f0, LEN - 1);
     const float *fill_p = fsrc + (ptrdiff_t)fp * mstride;
+    // (full 128-float slots: ONE 16-byte-per-lane DMA fills both slots of the pair, lanes 0..31 the first position,
+    //  lanes 32..63 the second -- issuing a fill instruction costs a wave hundreds of cycles, whatever its width)
+    constexpr bool FILL_X4 = FULLD && VEC == 2;
+    constexpr int NFILL = FILL_X4 ? 1 : 2 * VEC;   // fill instructions per wave and iteration
+    const float *fill_p4 = src + lbase + (lane & 31) * 4 + (ptrdiff_t)fp * mstride;
+    const ptrdiff_t second = (lane >> 5) ? (ptrdiff_t)mstride : (ptrdiff_t)0;
     float *out_p = dst + lbase + lane * VEC + (ptrdiff_t)(2 * wave - B * nlead) * mstride;   // (stored to inside the line only)
-    // This wave's pair descriptors travel like the fills: by LDS-DMA, two iterations ahead of their use, into a
-    // small staging area (two 32-byte slots per wave, used alternately): lanes 0..3 move the stage-1 record, lane 4
-    // the stage-2 descriptor. They are issued in front of the iteration's fills, so the wait for those fills
-    // covers them; the wave then reads its slot (every lane the same address) and makes the values uniform
-    // registers with v_readfirstlane. Scalar loads would be the natural form, but they share the LDS's wait counter
-    // and return out of order: the first wait for a ring read would sit out the whole scalar load. Ordinary vector
-    // loads would make the compiler wait for every fill in flight in front of their first use.
+    // The workgroup's pair descriptors travel like the fills: by LDS-DMA, two iterations ahead of their use, into a
+    // small staging area behind the rings (three 512-byte buffers used in turn: one being read, one landed, one in
+    // flight). ONE instruction of wave 0 moves
+    // them all: lanes 0..15 bring the stage-1 records of the 16 waves (consecutive pairs: 256 contiguous bytes),
+    // lanes 16..31 the stage-2 records. It is issued in front of that wave's fill, so the wait for the fill
+    // covers it, and the barrier that publishes the fills publishes the descriptors; behind that barrier every wave
+    // reads its own records (every lane the same address) and makes the values uniform registers with v_readfirstlane. Scalar
+    // loads would be the natural form, but they share the LDS's wait counter and return out of order: the first wait
+    // for a ring read would sit out the whole scalar load. Ordinary vector loads would make the compiler wait for
+    // every fill in flight in front of their first use. (An LDS-DMA instruction costs the CU some tens of cycles
+    // whatever it moves, and all waves of the CU queue for that: one per wave and iteration doubled the queue.)
     const size_t drow = (size_t)line * (((LEN + 1) >> 1) + 2 * dpad) + dpad;
-    const uint4 *d1p = desc + drow + ((pa >> 1) + wave);                  // stage-1 pair of the first iteration
-    const uint4 *d2p = desc + drow + (wave - (B * nlead) / 2);            // stage-2 pair of the first iteration
-    const uint32_t *dsrc = lane < 4 ? reinterpret_cast<const uint32_t *>(d1p) + lane : reinterpret_cast<const uint32_t *>(d2p);
-    float *const stage = ring2 + (size_t)R2 * SLOT + wave * 16;           // this wave's two slots of 8 dwords
-    const uint32_t stage_off = (uint32_t)(uintptr_t)stage;
-    auto desc_dma = [&](int it_ahead, int slot) {   // the descriptors `it_ahead` iterations ahead of dsrc into slot `slot`
-        if (lane < 5)
-            __builtin_amdgcn_global_load_lds(dsrc + (ptrdiff_t)it_ahead * (B / 2) * 4,
-                                             (__attribute__((address_space(3))) void *)(stage + slot * 8), 4, 0, 0);
+    const uint4 *d1p = desc + drow + (pa >> 1);                    // stage-1 pairs of the first iteration
+    const uint4 *d2p = desc + drow - (B * nlead) / 2;              // stage-2 pairs of the first iteration
+    const uint4 *dsrc = (lane < 16 ? d1p : d2p) + (lane & 15);
+    float *const stage = ring2 + (size_t)R2 * SLOT;                // three buffers of 128 dwords
+    const uint32_t stage_off = (uint32_t)(uintptr_t)stage + (uint32_t)wave * 16u;
+    auto desc_dma = [&](int it_ahead, int buf) {   // the descriptors `it_ahead` iterations ahead of dsrc into buffer `buf`
+        if (wave == 0 && lane < 32)
+            __builtin_amdgcn_global_load_lds(dsrc + (ptrdiff_t)it_ahead * (B / 2),
+                                             (__attribute__((address_space(3))) void *)(stage + buf * 128), 16, 0, 0);
     };
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
-    // (the slot is read through an address rebuilt from an integer, like the rings: ordering against the DMA is
-    // what the counted waits provide)
-    auto read_slot = [&](int slot, u32x4 &a, uint32_t &b) {
+    // (the buffer is read through an address rebuilt from an integer, like the rings: ordering against the DMA is
+    // what the counted waits and the barrier provide)
+    auto read_slot = [&](int buf, u32x4 &a, uint32_t &b) {
         typedef const volatile u32x4 __attribute__((address_space(3))) *p4;
         typedef const volatile uint32_t __attribute__((address_space(3))) *p1;
-        a = *(p4)(uintptr_t)(stage_off + slot * 32);
-        b = *(p1)(uintptr_t)(stage_off + slot * 32 + 16);
+        a = *(p4)(uintptr_t)(stage_off + buf * 512);
+        b = *(p1)(uintptr_t)(stage_off + buf * 512 + 256);
     };
     desc_dma(0, 0);
     desc_dma(1, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     u32x4 d1v;
     uint32_t d2v;
     read_slot(0, d1v, d2v);
     uint4 d1c = make_uint4(uni(d1v.x), uni(d1v.y), uni(d1v.z), 0u);
     uint32_t d2c = uni(d2v);
-    int nstore_prev = 0, par = 0;                 // par: the staging slot holding the NEXT iteration's descriptors is 1 - par
+    int nstore_prev = 0, sb = 0, sb2 = 2;         // staging buffers: sb holds this iteration's descriptors, sb2 takes the DMA
 
+#ifdef AGG_STAMP
+    unsigned long long st[8] = {}, tprev = __builtin_readcyclecounter();
+#endif
     for (int o0 = -B * nlead; o0 < LEN; o0 += B) {
-        // (a) the descriptors of the iteration after the next into the slot this iteration's came from, then the fills
-        desc_dma(2, par);
+        // (a) the descriptors of the iteration after the next into the staging buffer that is free, then the fill.
+        //     (Issuing the fills of half the waves between the stages instead, so that their queueing for the CU's
+        //     DMA path overlaps the other half's sums, moved time between the phases of an iteration and left its
+        //     length as it was.)
+        desc_dma(2, sb2);
         {
             const float *p1 = fill_p + (fp + 1 < LEN ? (ptrdiff_t)mstride : (ptrdiff_t)0);
             __builtin_amdgcn_s_setprio(3);
-            if constexpr (FULLD && VEC == 2) {
-                ring_fill(fill_p, ring + qf * SLOT);
-                ring_fill_hi(fill_p, ring + qf * SLOT);
-                ring_fill(p1, ring + (qf + 1) * SLOT);
-                ring_fill_hi(p1, ring + (qf + 1) * SLOT);
+            if constexpr (FILL_X4) {
+                ring_fill_x4(fill_p4 + (fp + 1 < LEN ? second : (ptrdiff_t)0), ring + qf * SLOT);
             } else {
 #pragma unroll
                 for (int h = 0; h < VEC; h++) {
@@ -743,6 +771,7 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
             }
             __builtin_amdgcn_s_setprio(0);
         }
+        STAMP(0)
         // (b) stage 1: A of positions p, p + 1 into ring 2
         if (d1c.x) {
             vec_t acc0, acc1;
@@ -754,6 +783,7 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
                 *(lds_vec_ptr)(uintptr_t)(rl2 + (qw + 1) * SLOT) = acc1;
             }
         }
+        STAMP(1)
         // (c) stage 2: outputs o, o + 1 from ring 2 (written before the previous barrier)
         int nstore = 0;
         if (d2c) {
@@ -766,32 +796,57 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
             }
             nstore = two ? 2 : 1;
         }
+        STAMP(2)
         // (d) the fills of the PREVIOUS iteration must have landed before the next iteration reads them (and with
         //     them the descriptors issued in front of them, which are the next iteration's). Issued since then, in
-        //     order: that iteration's stores, this one's descriptor DMA, its fills and its stores -- 2 + 1 + 2*VEC + 2
-        //     operations in the steady state, and never fewer than 1 + 2*VEC.
+        //     order: that iteration's stores, this one's descriptor DMA, its fills and its stores -- 2 + 1 + NFILL + 2
+        //     operations in the steady state, and never fewer than 1 + NFILL (wave 0; the others issue no descriptor DMA).
         if constexpr (FULLD) {
-            if (nstore == 2 && nstore_prev == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 + 2 * VEC) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 + 2 * VEC) : "memory");
+            if (wave == 0) {
+                if (nstore == 2 && nstore_prev == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 + NFILL) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 + NFILL) : "memory");
+            } else {
+                if (nstore == 2 && nstore_prev == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NFILL) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NFILL) : "memory");
+            }
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (lane-predicated fills: their number is not fixed)
         }
         nstore_prev = nstore;
-        read_slot(1 - par, d1v, d2v);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d1v), "+v"(d2v) : : "memory");
-        d1c = make_uint4(uni(d1v.x), uni(d1v.y), uni(d1v.z), 0u);
-        d2c = uni(d2v);
-        par = 1 - par;
+        STAMP(3)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's ring-2 slots are written
         __builtin_amdgcn_s_barrier();
+        STAMP(4)
+        sb2 = sb;
+        sb = sb == 2 ? 0 : sb + 1;
+        read_slot(sb, d1v, d2v);                             // the next iteration's descriptors (wave 0 brought them)
         q1 += B; if (q1 >= R1) q1 -= R1;
         qf += B; if (qf >= R1) qf -= R1;
         qw += B; if (qw >= R2) qw -= R2;
         q2 += B; if (q2 >= R2) q2 -= R2;
-        if (fp + B < LEN) { fp += B; fill_p += blk_m; }
+        if (fp + B < LEN) { fp += B; fill_p += blk_m; fill_p4 += blk_m; }
         out_p += blk_m;
-        dsrc += (B / 2) * 4;
+        dsrc += B / 2;
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d1v), "+v"(d2v) : : "memory");
+        d1c = make_uint4(uni(d1v.x), uni(d1v.y), uni(d1v.z), 0u);
+        d2c = uni(d2v);
+        STAMP(5)
     }
+#ifdef AGG_STAMP
+    if (lane == 0) {
+        for (int i = 0; i < 6; i++) atomicAdd(&g_agg_stamp[i], st[i]);
+        atomicAdd(&g_agg_stamp[7], 1ull);
+    }
+#endif
 }
+#ifdef AGG_STAMP
+extern "C" int adc_debug_agg_stamps(unsigned long long *out) {
+    unsigned long long z[8] = {};
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_agg_stamp), sizeof(z));
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_agg_stamp), z, sizeof(z));
+    return (int)e;
+}
+#endif
 
 // Fallback without LDS (any arm cap): one wave per (position, 64 disparities), spans re-read through
 // the caches. Same addition order.
@@ -927,7 +982,7 @@ bool aggregate_pair_fusion_supported(const Geom &g, int max_arm) {
     const char *str = std::getenv("ADC_AGG_FUSE");      // (test hook: 0 never, 2 whatever the frame size)
     const int env = str ? std::atoi(str) : 1;
     const int vec = (g.Dp >= 128 && g.Dp % 2 == 0) ? 2 : 1;
-    const size_t lds = (size_t)(4 * ((max_arm + 1) & ~1) + 5 * PAIR_B) * 64 * vec * 4 + AGG_WAVES * 64;
+    const size_t lds = (size_t)(4 * ((max_arm + 1) & ~1) + 5 * PAIR_B) * 64 * vec * 4 + 3 * 512;
     const long long chunks = (g.Dp + 64 * vec - 1) / (64 * vec);
     const long long wgs_min = chunks * (g.W < g.H ? g.W : g.H);
     const bool big = wgs_min >= 512 && (long long)g.W * g.H * g.Dp >= (32ll << 20);
@@ -943,7 +998,7 @@ void launch_aggregate_fused_pair(const float *src, float *dst, const uint4 *desc
     const int lines = vertical ? g.W : g.H;
     const int cap = (max_arm + 1) & ~1;                      // even (see the kernel)
     const int R1 = 2 * cap + 3 * PAIR_B, R2 = 2 * cap + 2 * PAIR_B;
-    const size_t lds = (size_t)(R1 + R2) * SLOT * sizeof(float) + AGG_WAVES * 64;   // + the descriptor staging slots
+    const size_t lds = (size_t)(R1 + R2) * SLOT * sizeof(float) + 3 * 512;   // + the descriptor staging buffers
     dim3 grid(chunks, lines), block(AGG_WAVES * 64);
     const bool fulld = g.Dp % SLOT == 0;
 #define ADC_FUSED_GO(V_, F_) k_agg_fused<V_, F_><<<grid, block, lds, s>>>(src, dst, desc, g.W, g.H, g.Dp, vertical, cap, R1, R2, pair_desc_pad(max_arm))

@@ -220,11 +220,7 @@ int do_initialize(adc_handle *h, int32_t W, int32_t H, const adc_option *opt, hi
     A(h->pl.cen_l, npx); A(h->pl.cen_r, npx);
     A(h->pl.step_l, npx); A(h->pl.step_r, npx);
     A(h->pl.arms, npx); A(h->pl.cnt_h, npx); A(h->pl.cnt_v, npx); A(h->pl.cnt_h32, npx); A(h->pl.cnt_v32, npx);
-    {
-        const size_t nrec = npx * (size_t)(2 * g.NV + 1);
-        A(h->pl.rec_hf, nrec); A(h->pl.rec_hb, nrec); A(h->pl.rec_v, nrec);
-        A(h->pl.rec_rows, (size_t)3 * g.H * scan_row_dwords(g));
-    }
+    A(h->pl.rec_rows, scan_rows_total_dwords(g)); A(h->pl.rec_base, scan_base_total_dwords(g));
     const int arm_cap = opt->cross_L1 < 0 ? 0 : (opt->cross_L1 < 255 ? opt->cross_L1 : 255);
     const size_t n_pair_h = pair_desc_count(H, W, arm_cap), n_pair_v = pair_desc_count(W, H, arm_cap);
     A(h->pl.pair_h, n_pair_h); A(h->pl.pair_v, n_pair_v);

@@ -32,8 +32,8 @@ struct Planes {
     uint32_t *arms;                 // left | right<<8 | top<<16 | bottom<<24
     uint16_t *cnt_h, *cnt_v;
     uint32_t *cnt_h32, *cnt_v32;    // same counts widened to 32 bits (dword scalar loads in the aggregation kernel)
-    uint32_t *rec_hf, *rec_hb, *rec_v;  // per-pixel colour-step records of the scanline passes, (2*NV+1) dwords each
-    uint32_t *rec_rows;                 // per-row packed right-image step flags the records are cut from (3 families)
+    uint32_t *rec_rows;                 // packed colour-step flag strings of the scanline passes: 3 families x rows x 32 shifted copies
+    uint32_t *rec_base;                 // the unshifted strings the copies are made from
     uint4 *pair_h, *pair_v;             // window descriptors of the position pairs of every row / column (fused aggregation)
 };
 
@@ -83,6 +83,8 @@ hipError_t scanline_setup_device();   // as aggregate_setup_device, for the scan
 // (d1,d2) reach tso.
 struct ScanParams { float P1[3]; float P2[3]; };
 int scan_row_dwords(const Geom &g);
+size_t scan_rows_total_dwords(const Geom &g);   // Planes::rec_rows
+size_t scan_base_total_dwords(const Geom &g);   // Planes::rec_base
 void launch_scan_records(const Planes &p, const Geom &g, hipStream_t s);
 // disp_wta != nullptr: also write the left-view WTA disparity of every pixel (last pass only).
 void launch_scanline_pass(const float *src, float *dst, const Planes &p, const Geom &g,

@@ -26,106 +26,120 @@
 
 namespace adc {
 
-// ---- colour-step records ----------------------------------------------------------------------------
+// ---- colour-step flags of a path pixel ---------------------------------------------------------------
 // For every pixel p and every disparity k the recurrence needs one bit: does d2 reach so_tso
 // (ADC/scanline_optimizer.cu:75-109)? d2 is the colour step of the RIGHT image at xr = x - k - dmin
 // along the path when 0 < xr < W-1, keeps the value of the previous disparity otherwise, and starts
 // as d1 (the LEFT image step). As k grows xr only decreases, so "previous value" is: d1 while
 // xr >= W-1 (nothing usable yet), and the step at xr = 1 once xr <= 0 -- or d1 for every k when not
-// even k = 0 reaches a usable column. All of this depends on the pixel only, so it is baked once per
-// frame into a record per pixel: 2*NV dwords of bits (bit k of the record = effective d2 flag) + one
-// dword whose bit 0 is the d1 flag. One table per path family: horizontal forward, horizontal
-// backward, vertical (the backward vertical pass reads the record one row further down, because the
-// pair (y, y+1) is stored at y+1).
+// even k = 0 reaches a usable column.
 //
-// Built in two steps. k_scan_rows packs, per image row and family, the right-image flags into a bit
-// string E indexed by j = (W-2) - xr, clamped to the usable columns (E[j] = flag at column
-// clamp(W-2-j, 1, W-2)): along a pixel's disparities j = (W-2-x+dmin) + k ascends with k, so a record
-// dword is 32 consecutive bits of E (one funnel shift), with the d1 flag in front while j < 0.
+// Per image row and path family (horizontal forward, horizontal backward, vertical) the right-image flags
+// are packed into a bit string E indexed by j = (W-2) - xr, clamped to the usable columns
+// (E[j] = flag at column clamp(W-2-j, 1, W-2)): along a pixel's disparities j = (W-2-x+dmin) + k ascends
+// with k, so the D flags of pixel x are D consecutive bits of its row's string, starting at j0 = W-2-x+dmin.
+// A second string F per row and family holds the LEFT image's d1 flag of pixel x at the same index j0.
+// Both strings are stored 32 times, copy c shifted down by c bits, so that a pixel finds its flags
+// dword-aligned in copy j0 & 31: the scanline kernels fetch 2*NV dwords of E and one dword of F per path pixel
+// by LDS-DMA straight from these strings (a few hundred KB per row family, cache resident) -- there is no
+// per-pixel table. What the strings cannot hold is the pixel's own d1 in place of the first disparities
+// (j < 0, or every disparity when no column is usable): only the few columns at the ends of a row have such
+// disparities, and the kernels patch them with a mask (rec_nfill / rec_apply_fill).
+//
+// Layout: [family][row][copy 0..31][E: ne dwords | F: ne dwords]. String index 0 <-> j = -joff (joff a multiple
+// of 32 that makes every pixel's start index non-negative).
+struct RecSrc {
+    const uint32_t *fam;   // this pass's family
+    int ne;                // dwords per string copy
+    int jbase;             // W - 2 + dmin + joff: pixel x starts at string index jbase - x
+    int dmin, D;
+};
+__device__ __forceinline__ uint32_t rec_index(const RecSrc &r, int x, int y) {   // dword index of pixel (x, y)'s first E dword
+    const int j = r.jbase - x;
+    return (uint32_t)(y * 32 + (j & 31)) * (uint32_t)(2 * r.ne) + (uint32_t)(j >> 5);
+}
+// number of leading disparities of a pixel in column x whose flag is the pixel's own d1 flag
+__device__ __forceinline__ int rec_nfill(const RecSrc &r, int x, int W) {
+    const int xhi = W - 2 + r.dmin;              // columns up to here have every disparity in the string
+    if (x > r.dmin && x <= xhi) return 0;        // (all but the ends of a row)
+    if (x <= r.dmin || W < 3) return r.D;
+    return min(x - xhi, r.D);
+}
+// kbits: the flags of disparities k0 .. k0+nv-1 (bit 0 = k0); the first nf disparities of the pixel take f1
+__device__ __forceinline__ uint32_t rec_apply_fill(uint32_t kbits, int nf, int k0, int nv, bool f1) {
+    const int c = min(max(nf - k0, 0), nv);
+    const uint32_t fm = (1u << c) - 1u;      // nv <= 16
+    return f1 ? (kbits | fm) : (kbits & ~fm);
+}
+
+// host side of the layout
+static int scan_joff(const Geom &g) { return 32 * ((std::max(0, 1 - g.dmin) + 31) / 32); }
+int scan_row_dwords(const Geom &g) {   // ne
+    return ((g.W - 2 + std::max(g.dmin, 0) + scan_joff(g)) >> 5) + 2 * g.NV + 2;
+}
+size_t scan_rows_total_dwords(const Geom &g) { return (size_t)3 * g.H * 64 * scan_row_dwords(g); }
+size_t scan_base_total_dwords(const Geom &g) { return (size_t)3 * g.H * 2 * (scan_row_dwords(g) + 1); }
+
+// unshifted strings: base[family][row][E | F][ne + 1]
 __global__ void __launch_bounds__(256)
-k_scan_rows(const uint8_t *__restrict__ step_r, uint32_t *__restrict__ erow, int W, int H, int ne) {
+k_scan_rows(const uint8_t *__restrict__ step_l, const uint8_t *__restrict__ step_r, uint32_t *__restrict__ base,
+            int W, int H, int dmin, int joff, int nb) {
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (size_t)H * ne) return;
-    const int y = (int)(gid / ne), jw = (int)(gid - (size_t)y * ne);
-    const uint8_t *rrow = step_r + (size_t)y * W;
-    uint32_t b_hf = 0, b_hb = 0, b_v = 0;
-    if (W >= 3) {
-        for (int b = 0; b < 32; b++) {
-            const int xc = min(max(W - 2 - (jw * 32 + b), 1), W - 2);
+    if (gid >= (size_t)H * nb) return;
+    const int y = (int)(gid / nb), iw = (int)(gid - (size_t)y * nb);
+    const uint8_t *rrow = step_r + (size_t)y * W, *lrow = step_l + (size_t)y * W;
+    uint32_t e_hf = 0, e_hb = 0, e_v = 0, f_hf = 0, f_hb = 0, f_v = 0;
+    for (int b = 0; b < 32; b++) {
+        const int j = iw * 32 + b - joff;
+        if (j >= 0 && W >= 3) {
+            const int xc = min(max(W - 2 - j, 1), W - 2);
             const uint32_t s0 = rrow[xc], s1 = rrow[xc + 1];
-            b_hf |= (s0 & 1u) << b;          // step between right pixels xc and xc-1
-            b_hb |= (s1 & 1u) << b;          // step between right pixels xc and xc+1
-            b_v |= ((s0 >> 1) & 1u) << b;    // step between rows y and y-1 at column xc
+            e_hf |= (s0 & 1u) << b;          // step between right pixels xc and xc-1
+            e_hb |= (s1 & 1u) << b;          // step between right pixels xc and xc+1
+            e_v |= ((s0 >> 1) & 1u) << b;    // step between rows y and y-1 at column xc
+        }
+        const int x = W - 2 + dmin - j;      // the left pixel whose disparities start at j
+        if (x >= 0 && x < W) {
+            const uint32_t sl = lrow[x];
+            f_hf |= (sl & 1u) << b;                                     // step between left pixels x and x-1
+            f_hb |= ((x + 1 < W) ? (uint32_t)(lrow[x + 1] & 1u) : 0u) << b;   // ... x and x+1
+            f_v |= ((sl >> 1) & 1u) << b;                               // ... rows y and y-1
         }
     }
-    const size_t fam = (size_t)H * ne;
-    erow[gid] = b_hf;
-    erow[fam + gid] = b_hb;
-    erow[2 * fam + gid] = b_v;
+    const size_t fam = (size_t)H * 2 * nb, row = (size_t)y * 2 * nb;
+    base[row + iw] = e_hf;            base[row + nb + iw] = f_hf;
+    base[fam + row + iw] = e_hb;      base[fam + row + nb + iw] = f_hb;
+    base[2 * fam + row + iw] = e_v;   base[2 * fam + row + nb + iw] = f_v;
 }
 
-// 32 bits of the string (f1 repeated for j < 0, then E) starting at bit jj
-__device__ __forceinline__ uint32_t rec_bits(const uint32_t *__restrict__ e, int jj, uint32_t f1) {
-    const uint32_t fill = f1 ? 0xffffffffu : 0u;
-    if (jj <= -32) return fill;
-    if (jj < 0) return (e[0] << (-jj)) | (fill >> (32 + jj));
-    const uint32_t lo = e[jj >> 5], hi = e[(jj >> 5) + 1];
-    return __funnelshift_r(lo, hi, jj & 31);
-}
-
+// the 32 shifted copies: out[family][row][c][E | F][ne], dword i of copy c = bits 32*i + c ... of the string
 __global__ void __launch_bounds__(256)
-k_scan_records(const uint8_t *__restrict__ step_l, const uint32_t *__restrict__ erow, uint32_t *__restrict__ rec_hf,
-               uint32_t *__restrict__ rec_hb, uint32_t *__restrict__ rec_v, int W, int H, int dmin, int D, int recw, int ne) {
+k_scan_copies(const uint32_t *__restrict__ base, uint32_t *__restrict__ out, int H, int ne) {
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)W * H * recw;
+    const size_t total = (size_t)3 * H * 64 * ne;
     if (gid >= total) return;
-    const size_t p = gid / recw;
-    const int w = (int)(gid - p * recw);
-    const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
-    const uint32_t sl = step_l[p];
-    const uint32_t f1_hf = sl & 1u;
-    const uint32_t f1_hb = (x + 1 < W) ? (step_l[p + 1] & 1u) : 0u;
-    const uint32_t f1_v = (sl >> 1) & 1u;
-    if (w == recw - 1) {
-        rec_hf[gid] = f1_hf;
-        rec_hb[gid] = f1_hb;
-        rec_v[gid] = f1_v;
-        return;
-    }
-    uint32_t b_hf = 0, b_hb = 0, b_v = 0;
-    const int nb = D - w * 32;                      // disparities this dword covers
-    if (nb > 0) {
-        const bool none = (x - dmin < 1) || (W < 3);   // no disparity of this pixel has 0 < xr < W-1
-        const int jj = none ? -32 : (W - 2 - x + dmin) + w * 32;
-        const size_t fam = (size_t)H * ne;
-        const uint32_t *e = erow + (size_t)y * ne;
-        b_hf = rec_bits(e, jj, f1_hf);
-        b_hb = rec_bits(e + fam, jj, f1_hb);
-        b_v = rec_bits(e + 2 * fam, jj, f1_v);
-        if (nb < 32) {
-            const uint32_t m = (1u << nb) - 1u;
-            b_hf &= m; b_hb &= m; b_v &= m;
-        }
-    }
-    rec_hf[gid] = b_hf;
-    rec_hb[gid] = b_hb;
-    rec_v[gid] = b_v;
-}
-
-// dwords per row and family of the packed flag strings: every j a record can reach, plus one dword
-int scan_row_dwords(const Geom &g) {
-    const long long jmax = (long long)g.W - 2 + (g.dmin > 0 ? g.dmin : 0) + g.D + 64;
-    return (int)(jmax / 32) + 2;
+    const int i = (int)(gid % ne);
+    const size_t t = gid / ne;               // ((family * H + row) * 32 + c) * 2 + part
+    const int part = (int)(t & 1), c = (int)((t >> 1) & 31);
+    const size_t fr = t >> 6;                // family * H + row
+    const uint32_t *b = base + (fr * 2 + part) * (size_t)(ne + 1) + i;
+    out[gid] = __funnelshift_r(b[0], b[1], c);
 }
 
 void launch_scan_records(const Planes &p, const Geom &g, hipStream_t s) {
-    const int recw = 2 * g.NV + 1;
+    const int ne = scan_row_dwords(g), nb = ne + 1;
+    const size_t nrow = (size_t)g.H * nb;
+    k_scan_rows<<<dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, s>>>(p.step_l, p.step_r, p.rec_base, g.W, g.H, g.dmin,
+                                                                          scan_joff(g), nb);
+    const size_t total = scan_rows_total_dwords(g);
+    k_scan_copies<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(p.rec_base, p.rec_rows, g.H, ne);
+}
+
+// the record source of a pass
+static RecSrc rec_source(const Planes &p, const Geom &g, int vertical, int forward) {
     const int ne = scan_row_dwords(g);
-    const size_t nrow = (size_t)g.H * ne;
-    k_scan_rows<<<dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, s>>>(p.step_r, p.rec_rows, g.W, g.H, ne);
-    const size_t total = (size_t)g.W * g.H * recw;
-    k_scan_records<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(p.step_l, p.rec_rows, p.rec_hf, p.rec_hb, p.rec_v,
-                                                                             g.W, g.H, g.dmin, g.D, recw, ne);
+    const int family = vertical ? 2 : (forward ? 0 : 1);
+    return RecSrc{p.rec_rows + (size_t)family * g.H * 64 * ne, ne, g.W - 2 + g.dmin + scan_joff(g), g.dmin, g.D};
 }
 
 // ---- the pass ----------------------------------------------------------------------------------------
@@ -226,7 +240,7 @@ template <int NV, bool WTA, int RSO = 0> struct ScanCfg {
 // One wavefront, one scanline: `line` is the row / column, `ring` this wave's RS x SLOT_B bytes of LDS.
 template <int NV, int VERT, bool FULL, bool WTA, int RSO = 0>
 __device__ __forceinline__ void
-scan_wave(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ rec,
+scan_wave(const float *__restrict__ src, float *__restrict__ dst, const RecSrc rec,
           float *__restrict__ disp, int W, int H, int dmin, int D, int Dp, int forward, const ScanParams &sp,
           int line, uint8_t *ring) {
     typedef ScanCfg<NV, WTA, RSO> C;
@@ -236,13 +250,13 @@ scan_wave(const float *__restrict__ src, float *__restrict__ dst, const uint32_t
     const int k0 = lane * NV;
     const bool active = FULL || k0 < Dp;       // lane owns part of the (padded) disparity vector
     const int koff = active ? k0 : 0;
-    const int recw = 2 * NV + 1;
-    // path head, per-step strides (in pixels), and the record shift of the backward vertical pass
+    // path head, per-step strides (in pixels); the backward vertical pass takes the flags of the row below
+    // (the step between rows y and y+1 is stored with row y+1)
     const int x0 = VERT ? line : (forward ? 0 : W - 1);
     const int y0 = VERT ? (forward ? 0 : H - 1) : line;
     const ptrdiff_t pstep = VERT ? (ptrdiff_t)dir * W : (ptrdiff_t)dir;
     const ptrdiff_t pix0 = (ptrdiff_t)y0 * W + x0;
-    const ptrdiff_t rshift = (VERT && !forward) ? (ptrdiff_t)W : 0;
+    const int yshift = (VERT && !forward) ? 1 : 0;
 
     // ---- fill addressing (lane <-> DMA element, which differs from the compute mapping for NV < 4)
     // data: NV >= 4: instruction q moves floats q*256 + 4*lane .. +3 (16 B per lane);
@@ -253,8 +267,10 @@ scan_wave(const float *__restrict__ src, float *__restrict__ dst, const uint32_t
     for (int q = 0; q < C::NDMA; q++) fok[q] = FULL || ((NV >= 4 ? q * 256 + 4 * lane : q * 64 + lane) < Dp);
     // the counted wait below assumes every one of the NDMA fill instructions has at least one live lane
     const bool counted = FULL || (Dp > (C::NDMA - 1) * (NV >= 4 ? 256 : 64));
-    const uint32_t *gflag = rec + lane;
-    const bool flag_lane = lane < recw;
+    // flags: lanes 0 .. 2*NV-1 fetch the E dwords of the pixel, lane 2*NV the F dword (ne dwords behind)
+    const uint32_t *gflag = rec.fam + (lane < 2 * NV ? lane : rec.ne);
+    const bool flag_lane = lane <= 2 * NV;
+    const int nf_col = VERT ? rec_nfill(rec, line, W) : 0;   // a column's pixels all patch the same disparities
 
     auto issue_fill = [&](int s) {     // path pixel s -> ring slot s % RS
         const ptrdiff_t p = pix0 + (ptrdiff_t)s * pstep;
@@ -269,8 +285,10 @@ scan_wave(const float *__restrict__ src, float *__restrict__ dst, const uint32_t
                     __builtin_amdgcn_global_load_lds(g + q * 64, (lds_void *)(slot + q * 256), 4, 0, 0);
             }
         }
-        if (flag_lane)
-            __builtin_amdgcn_global_load_lds(gflag + (size_t)(p + rshift) * recw, (lds_void *)(slot + C::DATA_B), 4, 0, 0);
+        if (flag_lane) {
+            const int fx = VERT ? line : x0 + dir * s, fy = VERT ? y0 + dir * s + yshift : line;
+            __builtin_amdgcn_global_load_lds(gflag + rec_index(rec, fx, fy), (lds_void *)(slot + C::DATA_B), 4, 0, 0);
+        }
     };
     // compute-side view of a slot. The reads go through an LDS address rebuilt from an integer: the
     // compiler then has no basis to tie them to the in-flight LDS-DMA fills (it would otherwise put a
@@ -360,7 +378,11 @@ scan_wave(const float *__restrict__ src, float *__restrict__ dst, const uint32_t
         if (s + 1 < LEN) read_slot(s + 1, nxt, nbits, nf1);
         // (D) the recurrence for pixel s
         const bool d1hi = cf1 & 1u;
-        const uint32_t kbits = cbits >> bshift;
+        uint32_t kbits = cbits >> bshift;
+        {
+            const int nf = VERT ? nf_col : rec_nfill(rec, x0 + dir * s, W);
+            if (nf) kbits = rec_apply_fill(kbits, nf, k0, NV, d1hi);
+        }
         const float P1a = d1hi ? sp.P1[1] : sp.P1[0], P1b = d1hi ? sp.P1[2] : sp.P1[1];
         const float P2a = d1hi ? sp.P2[1] : sp.P2[0], P2b = d1hi ? sp.P2[2] : sp.P2[1];
         const float up = dpp_f<0x138>(ADC_LARGE_F, Lp[NV - 1]);  // wave_shr:1 -> Lp[k0-1]
@@ -403,7 +425,7 @@ scan_wave(const float *__restrict__ src, float *__restrict__ dst, const uint32_t
 
 template <int NV, int VERT, bool FULL, bool WTA>
 __global__ void __launch_bounds__(256)
-k_scanline(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ rec,
+k_scanline(const float *__restrict__ src, float *__restrict__ dst, const RecSrc rec,
            float *__restrict__ disp, int W, int H, int dmin, int D, int Dp, int forward, ScanParams sp) {
     typedef ScanCfg<NV, WTA> C;
     extern __shared__ __align__(16) uint8_t lds_raw[];
@@ -456,7 +478,7 @@ template <int NVW, int NPARTS = 2, bool WTA = false> struct ScanCfgSplit {
 // disparity of every pixel, as scan_wave does.
 template <int NVW, int NPARTS, int VERT, bool WTA = false>
 __device__ __forceinline__ void
-scan_split_wave(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ rec,
+scan_split_wave(const float *__restrict__ src, float *__restrict__ dst, const RecSrc rec,
                 int W, int H, int Dp, int forward, const ScanParams &sp, int line, int part, uint32_t lds0,
                 float *__restrict__ disp = nullptr, int dmin = 0) {
     typedef ScanCfgSplit<NVW, NPARTS, WTA> C;
@@ -485,23 +507,26 @@ scan_split_wave(const float *__restrict__ src, float *__restrict__ dst, const ui
     const int dir = forward ? 1 : -1;
     const int kbase = part * 64 * NV;             // first disparity of this wave
     const int k0 = kbase + lane * NV;
-    const int recw = 2 * C::NVF + 1;
     const int x0 = VERT ? line : (forward ? 0 : W - 1);
     const int y0 = VERT ? (forward ? 0 : H - 1) : line;
     const ptrdiff_t pstep = VERT ? (ptrdiff_t)dir * W : (ptrdiff_t)dir;
     const ptrdiff_t pix0 = (ptrdiff_t)y0 * W + x0;
-    const ptrdiff_t rshift = (VERT && !forward) ? (ptrdiff_t)W : 0;
+    const int yshift = (VERT && !forward) ? 1 : 0;   // the backward vertical pass takes the flags of the row below
 
     // uniform byte addresses of path pixel 0 and the byte steps along the path
     const char *const src_b = reinterpret_cast<const char *>(src + (size_t)pix0 * Dp + kbase);
     char *const dst_b = reinterpret_cast<char *>(dst + (size_t)pix0 * Dp + kbase);
-    const char *const rec_b = reinterpret_cast<const char *>(rec + (size_t)(pix0 + rshift) * recw);
     const ptrdiff_t vstep = pstep * (ptrdiff_t)Dp * 4;
-    const ptrdiff_t rstep = pstep * (ptrdiff_t)recw * 4;
+    // the flags of path pixel t: uniform address of its first E dword (the F dword lies ne dwords behind)
+    auto rec_ptr = [&](int t) {
+        const int fx = VERT ? line : x0 + dir * t, fy = VERT ? y0 + dir * t + yshift : line;
+        return reinterpret_cast<const char *>(rec.fam + rec_index(rec, fx, fy));
+    };
+    const int nf_col = VERT ? rec_nfill(rec, line, W) : 0;
     const uint32_t vo_fill = (uint32_t)lane * (NV >= 4 ? 16u : 4u);
-    const uint32_t vo_rec = (uint32_t)lane * 4u;
+    const uint32_t vo_rec = (lane < 2 * C::NVF ? (uint32_t)lane : (uint32_t)rec.ne) * 4u;
     const uint32_t vo_out = (uint32_t)lane * (uint32_t)(NV * 4);
-    const bool flag_lane = lane < recw;
+    const bool flag_lane = lane <= 2 * C::NVF;
 
     auto issue_fill = [&](const char *sp_, const char *rp_, uint32_t slot) {
         lds_void *l = (lds_void *)(uintptr_t)(ring_off + slot);
@@ -602,7 +627,7 @@ scan_split_wave(const float *__restrict__ src, float *__restrict__ dst, const ui
     if (LEN < 2) return;
 
     for (int t = 1; t < RS && t < LEN; t++)
-        issue_fill(src_b + (ptrdiff_t)t * vstep, rec_b + (ptrdiff_t)t * rstep, (uint32_t)(t & (RS - 1)) * C::SLOT_B);
+        issue_fill(src_b + (ptrdiff_t)t * vstep, rec_ptr(t), (uint32_t)(t & (RS - 1)) * C::SLOT_B);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float ca[NV], cb[NV];
     uint32_t ba, fa, bb = 0, fb = 0;
@@ -614,7 +639,7 @@ scan_split_wave(const float *__restrict__ src, float *__restrict__ dst, const ui
                      float (&nxt)[NV], uint32_t &nbits, uint32_t &nf1) {
         if (FILL) {
             const int t = s + RS - 1;
-            issue_fill(src_b + (ptrdiff_t)t * vstep, rec_b + (ptrdiff_t)t * rstep, (uint32_t)(t & (RS - 1)) * C::SLOT_B);
+            issue_fill(src_b + (ptrdiff_t)t * vstep, rec_ptr(t), (uint32_t)(t & (RS - 1)) * C::SLOT_B);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::WAITN) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -627,7 +652,11 @@ scan_split_wave(const float *__restrict__ src, float *__restrict__ dst, const ui
             nbits = 0; nf1 = 0;
         }
         const bool d1hi = cf1 & 1u;
-        const uint32_t kbits = cbits >> bshift;
+        uint32_t kbits = cbits >> bshift;
+        {
+            const int nf = VERT ? nf_col : rec_nfill(rec, x0 + dir * s, W);
+            if (nf) kbits = rec_apply_fill(kbits, nf, k0, NV, d1hi);
+        }
         const float P1a = d1hi ? sp.P1[1] : sp.P1[0], P1b = d1hi ? sp.P1[2] : sp.P1[1];
         const float P2a = d1hi ? sp.P2[1] : sp.P2[0], P2b = d1hi ? sp.P2[2] : sp.P2[1];
         float up = dpp_f<0x138>(ADC_LARGE_F, Lp[NV - 1]);   // wave_shr:1 -> Lp[k0-1]
@@ -688,7 +717,7 @@ template <int NVW, int NPARTS> constexpr size_t scan_split_lds() {
 
 template <int NVW, int VERT>
 __global__ void __launch_bounds__(128)
-k_scanline_split2(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ rec,
+k_scanline_split2(const float *__restrict__ src, float *__restrict__ dst, const RecSrc rec,
                   int W, int H, int Dp, int forward, ScanParams sp) {
     extern __shared__ __align__(16) uint8_t lds_raw[];
     const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -699,7 +728,7 @@ k_scanline_split2(const float *__restrict__ src, float *__restrict__ dst, const 
 // disparity count fills the lanes exactly (Dp == D == 64*NV, NV <= 8). Four scanlines per workgroup.
 template <int NV, int VERT, bool WTA>
 __global__ void __launch_bounds__(256)
-k_scanline_lean(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ rec,
+k_scanline_lean(const float *__restrict__ src, float *__restrict__ dst, const RecSrc rec,
                 float *__restrict__ disp, int W, int H, int dmin, int Dp, int forward, ScanParams sp) {
     typedef ScanCfgSplit<NV, 1, WTA> C;
     extern __shared__ __align__(16) uint8_t lds_raw[];
@@ -719,7 +748,7 @@ k_scanline_lean(const float *__restrict__ src, float *__restrict__ dst, const ui
 #define HYB_RS 8
 #endif
 __global__ void __launch_bounds__(256)
-k_scanline_hybrid(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ rec,
+k_scanline_hybrid(const float *__restrict__ src, float *__restrict__ dst, const RecSrc rec,
                   int W, int H, int Dp, int forward, ScanParams sp, int rows_main) {
     typedef ScanCfg<4, false, HYB_RS> C;
     extern __shared__ __align__(16) uint8_t lds_raw[];
@@ -739,7 +768,7 @@ template <int NVW>
 static void launch_split(const float *src, float *dst, const Planes &p, const Geom &g, const ScanParams &sp,
                          int vertical, int forward, hipStream_t s) {
     const int nlines = vertical ? g.W : g.H;
-    const uint32_t *rec = vertical ? p.rec_v : (forward ? p.rec_hf : p.rec_hb);
+    const RecSrc rec = rec_source(p, g, vertical, forward);
     const size_t lds = scan_split_lds<NVW, 2>();
     if (vertical)
         k_scanline_split2<NVW, 1><<<dim3(nlines), dim3(128), lds, s>>>(src, dst, rec, g.W, g.H, g.Dp, forward, sp);
@@ -755,7 +784,7 @@ static void launch_nv(const float *src, float *dst, float *disp, const Planes &p
     dim3 grid((nlines + 3) / 4), block(256);
     const size_t lds = (size_t)4 * C::RS * C::SLOT_B;
     const bool full = (g.D == 64 * NV) && (g.Dp == g.D);
-    const uint32_t *rec = vertical ? p.rec_v : (forward ? p.rec_hf : p.rec_hb);
+    const RecSrc rec = rec_source(p, g, vertical, forward);
 #define ADC_SCAN(V, F) k_scanline<NV, V, F, WTA><<<grid, block, lds, s>>>(src, dst, rec, disp, g.W, g.H, g.dmin, g.D, g.Dp, forward, sp)
     if (vertical) { if (full) ADC_SCAN(1, true); else ADC_SCAN(1, false); }
     else { if (full) ADC_SCAN(0, true); else ADC_SCAN(0, false); }
@@ -816,7 +845,7 @@ void launch_scanline_pass(const float *src, float *dst, const Planes &p, const G
             rows_main = std::min(std::min(rows_main, simds), g.H - 1) & ~3;
             const size_t lds_main = (size_t)4 * C::RS * C::SLOT_B, lds_rest = scan_split_lds<1, 4>();
             k_scanline_hybrid<<<dim3(rows_main / 4 + (g.H - rows_main)), dim3(256), std::max(lds_main, lds_rest), s>>>(
-                src, dst, forward ? p.rec_hf : p.rec_hb, g.W, g.H, g.Dp, forward, sp, rows_main);
+                src, dst, rec_source(p, g, 0, forward), g.W, g.H, g.Dp, forward, sp, rows_main);
             return;
         }
     }
@@ -827,7 +856,7 @@ void launch_scanline_pass(const float *src, float *dst, const Planes &p, const G
     }
     if (g.Dp == g.D && g.D == 64 * g.NV && g.NV <= 8 && env_int("ADC_SCAN_LEAN", 1)) {
         const int nlines = vertical ? g.W : g.H;
-        const uint32_t *rec = vertical ? p.rec_v : (forward ? p.rec_hf : p.rec_hb);
+        const RecSrc rec = rec_source(p, g, vertical, forward);
         dim3 grid((nlines + 3) / 4), block(256);
 #define ADC_LEAN_K(N, V, T)                                                                                                 \
     do {                                                                                                                    \

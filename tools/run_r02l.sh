@@ -1,0 +1,5 @@
+set -o pipefail
+mkdir -p gpurun_out/r02l
+timeout -k 10 900 python -u -m pytest tests/test_parity_gpu.py -m gpu -x -q --timeout 300 --timeout-method thread -k "teddy or ragged or disparity_counts or tiny or option_variants or full_resolution or scanline or more_rows or cost_fused or negative or dmin" > gpurun_out/r02l/pytest.log 2>&1 || { tail -40 gpurun_out/r02l/pytest.log; exit 1; }
+tail -2 gpurun_out/r02l/pytest.log
+AB_STEPS=20 timeout -k 10 600 python tools/ab_bench.py base wta128 base wta128 2>&1 | tee gpurun_out/r02l/ab.txt
