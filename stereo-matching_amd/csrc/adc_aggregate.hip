@@ -593,6 +593,9 @@ __device__ __forceinline__ void desc_windows(typename VecT<VEC>::T &acc0, typena
                                              int q, uint32_t d) {
     typedef typename VecT<VEC>::T vec_t;
     constexpr int SLOT = 64 * VEC;
+#ifdef AGG_DIAG_ONE_TERM   // diagnostic: every window is one term (what is left is the kernel's memory skeleton)
+    d = (d & 0x80000000u) | (1u << 14);
+#endif
     const int hn = (d >> 7) & 127, mn = (d >> 14) & 255, tn = (d >> 22) & 127;
     const bool h1 = (d >> 29) & 1, t1 = (d >> 30) & 1;
     int u = q - (int)(d & 127);
@@ -760,6 +763,11 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
         {
             const float *p1 = fill_p + (fp + 1 < LEN ? (ptrdiff_t)mstride : (ptrdiff_t)0);
             __builtin_amdgcn_s_setprio(3);
+#ifdef AGG_DIAG_NO_MEM   // diagnostic: the fill reads one and the same line (cache hits), the stores are dropped
+            if constexpr (FILL_X4) {
+                ring_fill_x4(src + lbase + (lane & 31) * 4, ring + qf * SLOT);
+            } else
+#endif
             if constexpr (FILL_X4) {
                 ring_fill_x4(fill_p4 + (fp + 1 < LEN ? second : (ptrdiff_t)0), ring + qf * SLOT);
             } else {
@@ -790,11 +798,16 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
             vec_t acc0, acc1;
             desc_windows<VEC>(acc0, acc1, rl2, R2, q2, d2c);
             const bool two = d2c >> 31;
+#ifdef AGG_DIAG_NO_MEM
+            if (reinterpret_cast<float &>(acc0) == -1.f) *reinterpret_cast<vec_t *>(out_p) = acc0 + acc1;   // (never true)
+            nstore = 0;
+#else
             if (kok) {
                 *reinterpret_cast<vec_t *>(out_p) = acc0;
                 if (two) *reinterpret_cast<vec_t *>(out_p + mstride) = acc1;
             }
             nstore = two ? 2 : 1;
+#endif
         }
         STAMP(2)
         // (d) the fills of the PREVIOUS iteration must have landed before the next iteration reads them (and with

@@ -14,7 +14,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 // MODE 0: one dependent chain of v_pk_add_f32          1: two interleaved chains of v_pk_add_f32
 //      2: one dependent chain of v_add_f32             3: four independent chains of v_pk_add_f32
 //      4: ds_read_b64 only (16 in flight, then wait)   5: 16 x ds_read_b64, then 16 x (2 pk adds) with counted waits
-//      6: s_add_u32 chain (SALU)                       7: pattern 5 plus 16 SALU instructions in between
+//      7: pattern 5 plus 16 SALU instructions in between
 template <int MODE>
 __global__ void __launch_bounds__(1024) k_probe(float *out, int iters) {
     extern __shared__ float lds[];
@@ -54,8 +54,6 @@ __global__ void __launch_bounds__(1024) k_probe(float *out, int iters) {
                 asm volatile("s_waitcnt lgkmcnt(%3)\n v_pk_add_f32 %0, %0, %2\n v_pk_add_f32 %1, %1, %2\n"
                              : "+v"(a), "+v"(b) : "v"(r[u]), "n"(15 - u));
             }
-        } else if (MODE == 6) {
-            asm volatile(REP16("s_add_u32 %0, %0, 1\n") : "+s"(sacc));
         }
     }
     a += b + c + d;
@@ -94,7 +92,6 @@ int main() {
     run<1>("v_pk_add_f32, two interleaved chains", 32, cus, out);
     run<3>("v_pk_add_f32, four interleaved chains", 64, cus, out);
     run<2>("v_add_f32, one dependent chain", 16, cus, out);
-    run<6>("s_add_u32, one dependent chain", 16, cus, out);
     run<4>("ds_read_b64 x16, wait for all", 16, cus, out);
     run<5>("ds_read_b64 x16 + 32 v_pk_add_f32 (counted waits)", 48, cus, out);
     run<7>("the same + 16 s_add_u32", 64, cus, out);
