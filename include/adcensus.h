@@ -109,7 +109,9 @@ typedef enum adc_stage_id {
  * the launch stream around every launch). The reference times whole stages only (ADC/ADCensusStereo.cu:76-143). */
 typedef enum adc_kernel_id {
     ADC_KERNEL_COST = 0,     /* initial cost volume as a kernel of its own (0 ms when it is fused into AGGR0) */
-    ADC_KERNEL_AGGR0 = 1,    /* aggregation passes 0..7: ids 1..8 (H,V | V,H | H,V | V,H; odd passes divide)   */
+    ADC_KERNEL_AGGR0 = 1,    /* aggregation passes 0..7: ids 1..8 (H,V | V,H | H,V | V,H; odd passes divide). A launch
+                                that runs two passes (1+2, 3+4, 5+6) reports its time under the first of them and
+                                leaves the second at 0 ms */
     ADC_KERNEL_SCAN0 = 9,    /* scanline passes 0..3: ids 9..12 (left-right, right-left, up-down, down-up)     */
     ADC_KERNEL_WTA_RIGHT = 13,
     ADC_KERNEL_COUNT_ = 14
