@@ -39,29 +39,50 @@ namespace adc {
 // (E[j] = flag at column clamp(W-2-j, 1, W-2)): along a pixel's disparities j = (W-2-x+dmin) + k ascends
 // with k, so the D flags of pixel x are D consecutive bits of its row's string, starting at j0 = W-2-x+dmin.
 // A second string F per row and family holds the LEFT image's d1 flag of pixel x at the same index j0.
-// Both strings are stored 32 times, copy c shifted down by c bits, so that a pixel finds its flags
-// dword-aligned in copy j0 & 31: the scanline kernels fetch 2*NV dwords of E and one dword of F per path pixel
-// by LDS-DMA straight from these strings (a few hundred KB per row family, cache resident) -- there is no
-// per-pixel table. What the strings cannot hold is the pixel's own d1 in place of the first disparities
-// (j < 0, or every disparity when no column is usable): only the few columns at the ends of a row have such
-// disparities, and the kernels patch them with a mask (rec_nfill / rec_apply_fill).
+// The kernels do not read the strings themselves but what is cut from them once per frame, in one of two forms
+// chosen by the disparity count (a window = 32 consecutive bits of a string, i.e. the string funnel-shifted):
+//   records per pixel (NV <= 2)  for every pixel the 2*NV windows of E that hold its D flags, with the pixel's own d1
+//                      in place of the first disparities where the string has nothing to offer (j < 0, or every
+//                      disparity when no column is usable), and a dword whose bit 0 is d1. One contiguous fetch per
+//                      path pixel whose address steps by a constant along any path: the least work per pixel, which
+//                      is what the short serial chains of small frames are made of. (3 families x W x H x (2*NV+1)
+//                      dwords: 6 MB at 450 x 375.)
+//   windows by shift (NV >= 4)   per row and family 32 copies of the two strings, copy c shifted by c bits: window j
+//                      is dword j >> 5 of copy j & 31, so the windows of a pixel are consecutive dwords of one copy,
+//                      fetched by LDS-DMA straight from the copies -- no per-pixel table (it would take 224 MB at
+//                      1920 x 1080 x 256; the copies take 57 MB). The address cycles through the copies along a row,
+//                      and the few disparities at the ends of a row whose flag is the pixel's own d1 are patched in
+//                      the kernels with a mask (rec_nfill / rec_apply_fill). Large frames are bound by memory
+//                      traffic, not by the chain, and do not feel either.
 //
-// Layout: [family][row][copy 0..31][E: ne dwords | F: ne dwords]. String index 0 <-> j = -joff (joff a multiple
-// of 32 that makes every pixel's start index non-negative).
+// Layout: [family][row][x][2*NV + 1] (records) or [family][row][shift 0..31][E | F][ne] (windows by shift).
+// String index 0 <-> j = -joff (joff a multiple of 32 that makes every pixel's start index non-negative).
 struct RecSrc {
     const uint32_t *fam;   // this pass's family
-    int ne;                // dwords per string copy
-    int jbase;             // W - 2 + dmin + joff: pixel x starts at string index jbase - x
+    int ne;                // dwords per string (32 * ne windows)
+    int jbase;             // W - 2 + dmin + joff: pixel x starts at window jbase - x
     int dmin, D;
+    int row;               // dwords per image row of the family's table
 };
-__device__ __forceinline__ uint32_t rec_index(const RecSrc &r, int x, int y) {   // dword index of pixel (x, y)'s first E dword
+// the form of the table follows from the floats per lane of a pixel's disparities (Geom::NV)
+__host__ __device__ constexpr bool rec_per_pixel(int nv) { return nv <= 2; }
+__host__ __device__ constexpr int rec_row_dwords(int nv, int ne, int W) { return rec_per_pixel(nv) ? W * (2 * nv + 1) : 64 * ne; }
+template <int NVR>   // NVR: Geom::NV
+__device__ __forceinline__ uint32_t rec_index(const RecSrc &r, int x, int y) {   // index of pixel (x, y)'s first E window
+    if (rec_per_pixel(NVR)) return (uint32_t)y * (uint32_t)r.row + (uint32_t)(x * (2 * NVR + 1));
     const int j = r.jbase - x;
     return (uint32_t)(y * 32 + (j & 31)) * (uint32_t)(2 * r.ne) + (uint32_t)(j >> 5);
+}
+// what DMA lane `lane` of a pixel's 2*NVR + 1 adds to that index: E window number `lane`, or the F window
+template <int NVR>
+__device__ __forceinline__ uint32_t rec_lane_offset(const RecSrc &r, int lane) {
+    if (rec_per_pixel(NVR)) return (uint32_t)lane;
+    return lane < 2 * NVR ? (uint32_t)lane : (uint32_t)r.ne;
 }
 // number of leading disparities of a pixel in column x whose flag is the pixel's own d1 flag
 __device__ __forceinline__ int rec_nfill(const RecSrc &r, int x, int W) {
     const int xhi = W - 2 + r.dmin;              // columns up to here have every disparity in the string
-    if (x > r.dmin && x <= xhi) return 0;        // (all but the ends of a row)
+    if ((unsigned)(x - r.dmin - 1) < (unsigned)max(W - 2, 0)) return 0;   // dmin < x <= xhi: all but the ends of a row
     if (x <= r.dmin || W < 3) return r.D;
     return min(x - xhi, r.D);
 }
@@ -77,42 +98,48 @@ static int scan_joff(const Geom &g) { return 32 * ((std::max(0, 1 - g.dmin) + 31
 int scan_row_dwords(const Geom &g) {   // ne
     return ((g.W - 2 + std::max(g.dmin, 0) + scan_joff(g)) >> 5) + 2 * g.NV + 2;
 }
-size_t scan_rows_total_dwords(const Geom &g) { return (size_t)3 * g.H * 64 * scan_row_dwords(g); }
+size_t scan_rows_total_dwords(const Geom &g) { return (size_t)3 * g.H * rec_row_dwords(g.NV, scan_row_dwords(g), g.W); }
 size_t scan_base_total_dwords(const Geom &g) { return (size_t)3 * g.H * 2 * (scan_row_dwords(g) + 1); }
 
-// unshifted strings: base[family][row][E | F][ne + 1]
+// unshifted strings: base[family][row][E | F][nb], nb = ne + 1. One lane per bit (64 bits = two dwords per wave),
+// gathered by ballot.
 __global__ void __launch_bounds__(256)
 k_scan_rows(const uint8_t *__restrict__ step_l, const uint8_t *__restrict__ step_r, uint32_t *__restrict__ base,
             int W, int H, int dmin, int joff, int nb) {
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (size_t)H * nb) return;
-    const int y = (int)(gid / nb), iw = (int)(gid - (size_t)y * nb);
+    const int lane = threadIdx.x & 63;
+    const int pairs = (nb + 1) >> 1;                       // 64-bit pieces per string
+    const size_t wid = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (wid >= (size_t)H * pairs) return;                  // (whole waves leave together)
+    const int y = (int)(wid / pairs), iw = 2 * (int)(wid - (size_t)y * pairs);
     const uint8_t *rrow = step_r + (size_t)y * W, *lrow = step_l + (size_t)y * W;
-    uint32_t e_hf = 0, e_hb = 0, e_v = 0, f_hf = 0, f_hb = 0, f_v = 0;
-    for (int b = 0; b < 32; b++) {
-        const int j = iw * 32 + b - joff;
-        if (j >= 0 && W >= 3) {
-            const int xc = min(max(W - 2 - j, 1), W - 2);
-            const uint32_t s0 = rrow[xc], s1 = rrow[xc + 1];
-            e_hf |= (s0 & 1u) << b;          // step between right pixels xc and xc-1
-            e_hb |= (s1 & 1u) << b;          // step between right pixels xc and xc+1
-            e_v |= ((s0 >> 1) & 1u) << b;    // step between rows y and y-1 at column xc
-        }
-        const int x = W - 2 + dmin - j;      // the left pixel whose disparities start at j
-        if (x >= 0 && x < W) {
-            const uint32_t sl = lrow[x];
-            f_hf |= (sl & 1u) << b;                                     // step between left pixels x and x-1
-            f_hb |= ((x + 1 < W) ? (uint32_t)(lrow[x + 1] & 1u) : 0u) << b;   // ... x and x+1
-            f_v |= ((sl >> 1) & 1u) << b;                               // ... rows y and y-1
-        }
+    const int j = iw * 32 + lane - joff;
+    bool e_hf = false, e_hb = false, e_v = false, f_hf = false, f_hb = false, f_v = false;
+    if (j >= 0 && W >= 3) {
+        const int xc = min(max(W - 2 - j, 1), W - 2);
+        const uint32_t s0 = rrow[xc], s1 = rrow[xc + 1];
+        e_hf = s0 & 1u;            // step between right pixels xc and xc-1
+        e_hb = s1 & 1u;            // step between right pixels xc and xc+1
+        e_v = (s0 >> 1) & 1u;      // step between rows y and y-1 at column xc
     }
-    const size_t fam = (size_t)H * 2 * nb, row = (size_t)y * 2 * nb;
-    base[row + iw] = e_hf;            base[row + nb + iw] = f_hf;
-    base[fam + row + iw] = e_hb;      base[fam + row + nb + iw] = f_hb;
-    base[2 * fam + row + iw] = e_v;   base[2 * fam + row + nb + iw] = f_v;
+    const int x = W - 2 + dmin - j;                        // the left pixel whose disparities start at j
+    if (x >= 0 && x < W) {
+        const uint32_t sl = lrow[x];
+        f_hf = sl & 1u;                                    // step between left pixels x and x-1
+        f_hb = (x + 1 < W) ? (lrow[x + 1] & 1u) : false;   // ... x and x+1
+        f_v = (sl >> 1) & 1u;                              // ... rows y and y-1
+    }
+    const unsigned long long m0 = __ballot(e_hf), m1 = __ballot(f_hf), m2 = __ballot(e_hb), m3 = __ballot(f_hb),
+                             m4 = __ballot(e_v), m5 = __ballot(f_v);
+    // lanes 0..5 store the low dwords of the six strings, lanes 8..13 the high dwords
+    const int k = lane & 7, hi = lane >> 3;
+    if (k < 6 && hi < 2 && iw + hi < nb) {
+        const unsigned long long m = k == 0 ? m0 : k == 1 ? m1 : k == 2 ? m2 : k == 3 ? m3 : k == 4 ? m4 : m5;
+        const size_t fam = (size_t)H * 2 * nb, row = (size_t)y * 2 * nb;
+        base[(size_t)(k >> 1) * fam + row + (size_t)(k & 1) * nb + iw + hi] = (uint32_t)(m >> (32 * hi));
+    }
 }
 
-// the 32 shifted copies: out[family][row][c][E | F][ne], dword i of copy c = bits 32*i + c ... of the string
+// the window tables: by shift, out[family * H + row][c][E | F][i] = bits 32 i + c ... of the string
 __global__ void __launch_bounds__(256)
 k_scan_copies(const uint32_t *__restrict__ base, uint32_t *__restrict__ out, int H, int ne) {
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -120,26 +147,60 @@ k_scan_copies(const uint32_t *__restrict__ base, uint32_t *__restrict__ out, int
     if (gid >= total) return;
     const int i = (int)(gid % ne);
     const size_t t = gid / ne;               // ((family * H + row) * 32 + c) * 2 + part
-    const int part = (int)(t & 1), c = (int)((t >> 1) & 31);
-    const size_t fr = t >> 6;                // family * H + row
-    const uint32_t *b = base + (fr * 2 + part) * (size_t)(ne + 1) + i;
+    const int c = (int)((t >> 1) & 31);
+    const size_t str = (t >> 6) * 2 + (t & 1);
+    const uint32_t *b = base + str * (size_t)(ne + 1) + i;
     out[gid] = __funnelshift_r(b[0], b[1], c);
+}
+// ... and records per pixel, out[family * H + row][x][w]: E windows j0 + 32 w for w < 2 nv with the pixel's own
+// d1 flag in front, then a dword holding d1
+__global__ void __launch_bounds__(256)
+k_scan_records(const uint32_t *__restrict__ base, uint32_t *__restrict__ out, int W, int H, int ne, int nv, int jbase,
+               int dmin, int D) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int recw = 2 * nv + 1;
+    const size_t per = (size_t)W * recw;
+    if (gid >= (size_t)3 * H * per) return;
+    const size_t fr = gid / per;             // family * H + row
+    const int k = (int)(gid - fr * per);
+    const int x = k / recw, w = k - x * recw;
+    const int j = jbase - x, i = j >> 5, c = j & 31;
+    const uint32_t *bf = base + (fr * 2 + 1) * (size_t)(ne + 1) + i;
+    const uint32_t f1 = (bf[0] >> c) & 1u;
+    uint32_t v = f1;
+    if (w < recw - 1) {
+        const uint32_t *be = base + (fr * 2) * (size_t)(ne + 1) + i + w;
+        v = __funnelshift_r(be[0], be[1], c);
+        // the leading disparities that take d1 (as rec_nfill counts them); this dword covers disparities 32 w ...
+        int nf = 0;
+        if (x - dmin < 1 || W < 3) nf = D;
+        else nf = min(max(x - (W - 2 + dmin), 0), D);
+        const int m = min(max(nf - 32 * w, 0), 32);
+        const uint32_t fm = m >= 32 ? 0xffffffffu : ((1u << m) - 1u);
+        v = f1 ? (v | fm) : (v & ~fm);
+    }
+    out[gid] = v;
 }
 
 void launch_scan_records(const Planes &p, const Geom &g, hipStream_t s) {
     const int ne = scan_row_dwords(g), nb = ne + 1;
-    const size_t nrow = (size_t)g.H * nb;
+    const size_t nrow = (size_t)g.H * ((nb + 1) / 2) * 64;   // a wave per 64 bits of a row's strings
     k_scan_rows<<<dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, s>>>(p.step_l, p.step_r, p.rec_base, g.W, g.H, g.dmin,
                                                                           scan_joff(g), nb);
     const size_t total = scan_rows_total_dwords(g);
-    k_scan_copies<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(p.rec_base, p.rec_rows, g.H, ne);
+    if (rec_per_pixel(g.NV))
+        k_scan_records<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(p.rec_base, p.rec_rows, g.W, g.H, ne, g.NV,
+                                                                                  g.W - 2 + g.dmin + scan_joff(g), g.dmin, g.D);
+    else
+        k_scan_copies<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(p.rec_base, p.rec_rows, g.H, ne);
 }
 
 // the record source of a pass
 static RecSrc rec_source(const Planes &p, const Geom &g, int vertical, int forward) {
     const int ne = scan_row_dwords(g);
     const int family = vertical ? 2 : (forward ? 0 : 1);
-    return RecSrc{p.rec_rows + (size_t)family * g.H * 64 * ne, ne, g.W - 2 + g.dmin + scan_joff(g), g.dmin, g.D};
+    const int row = rec_row_dwords(g.NV, ne, g.W);
+    return RecSrc{p.rec_rows + (size_t)family * g.H * row, ne, g.W - 2 + g.dmin + scan_joff(g), g.dmin, g.D, row};
 }
 
 // ---- the pass ----------------------------------------------------------------------------------------
@@ -267,8 +328,8 @@ scan_wave(const float *__restrict__ src, float *__restrict__ dst, const RecSrc r
     for (int q = 0; q < C::NDMA; q++) fok[q] = FULL || ((NV >= 4 ? q * 256 + 4 * lane : q * 64 + lane) < Dp);
     // the counted wait below assumes every one of the NDMA fill instructions has at least one live lane
     const bool counted = FULL || (Dp > (C::NDMA - 1) * (NV >= 4 ? 256 : 64));
-    // flags: lanes 0 .. 2*NV-1 fetch the E dwords of the pixel, lane 2*NV the F dword (ne dwords behind)
-    const uint32_t *gflag = rec.fam + (lane < 2 * NV ? lane : rec.ne);
+    // flags: lanes 0 .. 2*NV-1 fetch the E windows of the pixel, lane 2*NV its F window
+    const uint32_t *gflag = rec.fam + rec_lane_offset<NV>(rec, lane);
     const bool flag_lane = lane <= 2 * NV;
     const int nf_col = VERT ? rec_nfill(rec, line, W) : 0;   // a column's pixels all patch the same disparities
 
@@ -287,7 +348,7 @@ scan_wave(const float *__restrict__ src, float *__restrict__ dst, const RecSrc r
         }
         if (flag_lane) {
             const int fx = VERT ? line : x0 + dir * s, fy = VERT ? y0 + dir * s + yshift : line;
-            __builtin_amdgcn_global_load_lds(gflag + rec_index(rec, fx, fy), (lds_void *)(slot + C::DATA_B), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds(gflag + rec_index<NV>(rec, fx, fy), (lds_void *)(slot + C::DATA_B), 4, 0, 0);
         }
     };
     // compute-side view of a slot. The reads go through an LDS address rebuilt from an integer: the
@@ -379,7 +440,7 @@ scan_wave(const float *__restrict__ src, float *__restrict__ dst, const RecSrc r
         // (D) the recurrence for pixel s
         const bool d1hi = cf1 & 1u;
         uint32_t kbits = cbits >> bshift;
-        {
+        if constexpr (!rec_per_pixel(NV)) {
             const int nf = VERT ? nf_col : rec_nfill(rec, x0 + dir * s, W);
             if (nf) kbits = rec_apply_fill(kbits, nf, k0, NV, d1hi);
         }
@@ -517,14 +578,18 @@ scan_split_wave(const float *__restrict__ src, float *__restrict__ dst, const Re
     const char *const src_b = reinterpret_cast<const char *>(src + (size_t)pix0 * Dp + kbase);
     char *const dst_b = reinterpret_cast<char *>(dst + (size_t)pix0 * Dp + kbase);
     const ptrdiff_t vstep = pstep * (ptrdiff_t)Dp * 4;
-    // the flags of path pixel t: uniform address of its first E dword (the F dword lies ne dwords behind)
+    // the flags of path pixel t: uniform address of its first E window; a constant step along the path when the
+    // table is linear or the path a column
+    constexpr bool PER_PIXEL = rec_per_pixel(C::NVF);
+    const char *const rec_b = reinterpret_cast<const char *>(rec.fam + rec_index<C::NVF>(rec, x0, y0 + yshift));
+    const ptrdiff_t rstep = VERT ? (ptrdiff_t)dir * rec.row * 4 : (ptrdiff_t)dir * (2 * C::NVF + 1) * 4;
     auto rec_ptr = [&](int t) {
-        const int fx = VERT ? line : x0 + dir * t, fy = VERT ? y0 + dir * t + yshift : line;
-        return reinterpret_cast<const char *>(rec.fam + rec_index(rec, fx, fy));
+        if constexpr (VERT || PER_PIXEL) return rec_b + (ptrdiff_t)t * rstep;
+        else return reinterpret_cast<const char *>(rec.fam + rec_index<C::NVF>(rec, x0 + dir * t, line));
     };
     const int nf_col = VERT ? rec_nfill(rec, line, W) : 0;
     const uint32_t vo_fill = (uint32_t)lane * (NV >= 4 ? 16u : 4u);
-    const uint32_t vo_rec = (lane < 2 * C::NVF ? (uint32_t)lane : (uint32_t)rec.ne) * 4u;
+    const uint32_t vo_rec = rec_lane_offset<C::NVF>(rec, lane) * 4u;
     const uint32_t vo_out = (uint32_t)lane * (uint32_t)(NV * 4);
     const bool flag_lane = lane <= 2 * C::NVF;
 
@@ -635,7 +700,8 @@ scan_split_wave(const float *__restrict__ src, float *__restrict__ dst, const Re
 
     // one path pixel: costs/record of this pixel in (cur, cbits, cf1); the next pixel's are fetched into
     // (nxt, nbits, nf1). FILL / NEXT: the fill RS-1 pixels ahead / the next pixel exist.
-    auto pixel = [&](int s, uint32_t par, bool FILL, bool NEXT, const float (&cur)[NV], uint32_t cbits, uint32_t cf1,
+    // PATCH: the pixel may be one whose first disparities take its own d1 flag (the ends of a row).
+    auto pixel = [&](int s, uint32_t par, bool FILL, bool NEXT, bool PATCH, const float (&cur)[NV], uint32_t cbits, uint32_t cf1,
                      float (&nxt)[NV], uint32_t &nbits, uint32_t &nf1) {
         if (FILL) {
             const int t = s + RS - 1;
@@ -653,7 +719,7 @@ scan_split_wave(const float *__restrict__ src, float *__restrict__ dst, const Re
         }
         const bool d1hi = cf1 & 1u;
         uint32_t kbits = cbits >> bshift;
-        {
+        if (PATCH && !PER_PIXEL) {
             const int nf = VERT ? nf_col : rec_nfill(rec, x0 + dir * s, W);
             if (nf) kbits = rec_apply_fill(kbits, nf, k0, NV, d1hi);
         }
@@ -698,12 +764,33 @@ scan_split_wave(const float *__restrict__ src, float *__restrict__ dst, const Re
 
     int s = 1;
     // main part: every fill and every next pixel exists (s + 1 + RS - 1 < LEN for the second pixel of a trip)
-    for (; s + RS < LEN; s += 2) {
-        pixel(s, 1u, true, true, ca, ba, fa, cb, bb, fb);
-        pixel(s + 1, 0u, true, true, cb, bb, fb, ca, ba, fa);
+    if constexpr (PER_PIXEL) {
+        for (; s + RS < LEN; s += 2) {
+            pixel(s, 1u, true, true, false, ca, ba, fa, cb, bb, fb);
+            pixel(s + 1, 0u, true, true, false, cb, bb, fb, ca, ba, fa);
+        }
+    } else {
+        // path pixels s_lo <= s < s_hi have every flag in the strings (rec_nfill is 0 for them): all of a column, or a
+        // row without its ends
+        int s_lo = LEN, s_hi = LEN;
+        if (VERT) s_lo = nf_col ? LEN : 0;
+        else if (W >= 3 && forward) { s_lo = max(rec.dmin + 1, 0); s_hi = min(W - 1 + rec.dmin, W); }
+        else if (W >= 3) { s_lo = max(1 - rec.dmin, 0); s_hi = min(W - 1 - rec.dmin, W); }
+        for (; s + RS < LEN && s < s_lo; s += 2) {
+            pixel(s, 1u, true, true, true, ca, ba, fa, cb, bb, fb);
+            pixel(s + 1, 0u, true, true, true, cb, bb, fb, ca, ba, fa);
+        }
+        for (; s + RS < LEN && s + 1 < s_hi; s += 2) {
+            pixel(s, 1u, true, true, false, ca, ba, fa, cb, bb, fb);
+            pixel(s + 1, 0u, true, true, false, cb, bb, fb, ca, ba, fa);
+        }
+        for (; s + RS < LEN; s += 2) {
+            pixel(s, 1u, true, true, true, ca, ba, fa, cb, bb, fb);
+            pixel(s + 1, 0u, true, true, true, cb, bb, fb, ca, ba, fa);
+        }
     }
     for (; s < LEN; s++) {
-        pixel(s, (uint32_t)(s & 1), s + RS - 1 < LEN, s + 1 < LEN, ca, ba, fa, cb, bb, fb);
+        pixel(s, (uint32_t)(s & 1), s + RS - 1 < LEN, s + 1 < LEN, true, ca, ba, fa, cb, bb, fb);
 #pragma unroll
         for (int j = 0; j < NV; j++) ca[j] = cb[j];
         ba = bb; fa = fb;
