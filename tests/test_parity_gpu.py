@@ -480,11 +480,12 @@ def test_left_wta_fused_and_separate(pkg, orc, synth, monkeypatch, fused, D, dmi
     (64, 33, 0, 16, dict(cross_L1=5, cross_L2=2)),   # segments shorter than a block
     (40, 300, 0, 40, dict(cross_L1=40)),          # long columns, arms beyond the default
 ])
-def test_fused_aggregation_pairs(pkg, orc, synth, monkeypatch, W, H, dmin, dmax, opt):
-    """ADC_AGG_FUSE=2 runs the dividing pass and the same-axis pass behind it as one launch whatever the frame size
-    (by default only large frames do); every tap must still be the oracle's bits, with and without the taps'
-    separate cost kernel, and equal to the unfused pipeline's."""
-    monkeypatch.setenv("ADC_AGG_FUSE", "2")
+@pytest.mark.parametrize("fuse", ["1", "0"])
+def test_fused_aggregation_pairs(pkg, orc, synth, monkeypatch, W, H, dmin, dmax, opt, fuse):
+    """The dividing aggregation pass and the same-axis pass behind it run as one launch wherever the kernel's rings
+    fit the LDS (the default); ADC_AGG_FUSE=0 runs all eight passes on their own. Either way every tap must be the
+    oracle's bits, with and without the taps' separate cost kernel."""
+    monkeypatch.setenv("ADC_AGG_FUSE", fuse)
     L, R, _ = synth.pair(180, max(W, 16), max(H, 16), max(dmax - dmin, 8))
     L, R = np.ascontiguousarray(L[:H, :W]), np.ascontiguousarray(R[:H, :W])
     got = check_against_oracle(pkg, orc, L, R, min_disparity=dmin, max_disparity=dmax, **opt)
