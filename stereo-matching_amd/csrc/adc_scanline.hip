@@ -152,34 +152,37 @@ k_scan_copies(const uint32_t *__restrict__ base, uint32_t *__restrict__ out, int
     const uint32_t *b = base + str * (size_t)(ne + 1) + i;
     out[gid] = __funnelshift_r(b[0], b[1], c);
 }
-// ... and records per pixel, out[family * H + row][x][w]: E windows j0 + 32 w for w < 2 nv with the pixel's own
-// d1 flag in front, then a dword holding d1
+// ... and records per pixel, out[family][row][x][w]: E windows j0 + 32 w for w < 2 NVR with the pixel's own d1
+// flag in front, then a dword holding d1. One thread per (pixel, w) writes the dword of all three families.
+template <int NVR>
 __global__ void __launch_bounds__(256)
-k_scan_records(const uint32_t *__restrict__ base, uint32_t *__restrict__ out, int W, int H, int ne, int nv, int jbase,
-               int dmin, int D) {
+k_scan_records(const uint32_t *__restrict__ base, uint32_t *__restrict__ out, int W, int H, int ne, int jbase, int dmin, int D) {
+    constexpr int RECW = 2 * NVR + 1;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int recw = 2 * nv + 1;
-    const size_t per = (size_t)W * recw;
-    if (gid >= (size_t)3 * H * per) return;
-    const size_t fr = gid / per;             // family * H + row
-    const int k = (int)(gid - fr * per);
-    const int x = k / recw, w = k - x * recw;
+    const size_t per = (size_t)W * RECW;              // dwords per image row of a family
+    if (gid >= (size_t)H * per) return;
+    const int y = (int)(gid / per);
+    const int k = (int)(gid - (size_t)y * per);
+    const int x = k / RECW, w = k - x * RECW;
     const int j = jbase - x, i = j >> 5, c = j & 31;
-    const uint32_t *bf = base + (fr * 2 + 1) * (size_t)(ne + 1) + i;
-    const uint32_t f1 = (bf[0] >> c) & 1u;
-    uint32_t v = f1;
-    if (w < recw - 1) {
-        const uint32_t *be = base + (fr * 2) * (size_t)(ne + 1) + i + w;
-        v = __funnelshift_r(be[0], be[1], c);
-        // the leading disparities that take d1 (as rec_nfill counts them); this dword covers disparities 32 w ...
-        int nf = 0;
-        if (x - dmin < 1 || W < 3) nf = D;
-        else nf = min(max(x - (W - 2 + dmin), 0), D);
-        const int m = min(max(nf - 32 * w, 0), 32);
-        const uint32_t fm = m >= 32 ? 0xffffffffu : ((1u << m) - 1u);
-        v = f1 ? (v | fm) : (v & ~fm);
+    const size_t nb = (size_t)ne + 1, fam_in = (size_t)H * 2 * nb, fam_out = (size_t)H * per;
+    // the leading disparities that take d1 (as rec_nfill counts them); dword w covers disparities 32 w ...
+    int nf = 0;
+    if (x - dmin < 1 || W < 3) nf = D;
+    else nf = min(max(x - (W - 2 + dmin), 0), D);
+    const int m = min(max(nf - 32 * w, 0), 32);
+    const uint32_t fm = m >= 32 ? 0xffffffffu : ((1u << m) - 1u);
+#pragma unroll
+    for (int f = 0; f < 3; f++) {
+        const uint32_t *b = base + (size_t)f * fam_in + (size_t)y * 2 * nb;
+        const uint32_t f1 = (b[nb + i] >> c) & 1u;
+        uint32_t v = f1;
+        if (w < RECW - 1) {
+            v = __funnelshift_r(b[i + w], b[i + w + 1], c);
+            v = f1 ? (v | fm) : (v & ~fm);
+        }
+        out[(size_t)f * fam_out + gid] = v;
     }
-    out[gid] = v;
 }
 
 void launch_scan_records(const Planes &p, const Geom &g, hipStream_t s) {
@@ -188,10 +191,12 @@ void launch_scan_records(const Planes &p, const Geom &g, hipStream_t s) {
     k_scan_rows<<<dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, s>>>(p.step_l, p.step_r, p.rec_base, g.W, g.H, g.dmin,
                                                                           scan_joff(g), nb);
     const size_t total = scan_rows_total_dwords(g);
-    if (rec_per_pixel(g.NV))
-        k_scan_records<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(p.rec_base, p.rec_rows, g.W, g.H, ne, g.NV,
-                                                                                  g.W - 2 + g.dmin + scan_joff(g), g.dmin, g.D);
-    else
+    if (rec_per_pixel(g.NV)) {
+        const int jbase = g.W - 2 + g.dmin + scan_joff(g);
+        const dim3 grid((unsigned)((total / 3 + 255) / 256));
+        if (g.NV == 1) k_scan_records<1><<<grid, dim3(256), 0, s>>>(p.rec_base, p.rec_rows, g.W, g.H, ne, jbase, g.dmin, g.D);
+        else k_scan_records<2><<<grid, dim3(256), 0, s>>>(p.rec_base, p.rec_rows, g.W, g.H, ne, jbase, g.dmin, g.D);
+    } else
         k_scan_copies<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(p.rec_base, p.rec_rows, g.H, ne);
 }
 
@@ -497,6 +502,15 @@ k_scanline(const float *__restrict__ src, float *__restrict__ dst, const RecSrc 
                                    lds_raw + (size_t)wave * C::RS * C::SLOT_B);
 }
 
+// f(integral_constant<int, U>) for U = FROM .. TO-1, unrolled at compile time
+template <int FROM, int TO, class F>
+__device__ __forceinline__ void unroll_pixels(F &&f) {
+    if constexpr (FROM < TO) {
+        f(std::integral_constant<int, FROM>{});
+        unroll_pixels<FROM + 1, TO>(f);
+    }
+}
+
 // ---- several wavefronts per scanline --------------------------------------------------------------------
 // A pass is a serial chain per scanline. One wave per scanline is the cheapest way to run it, but the wave
 // count then has to fit the chip: a SIMD that gets a second full-width wave needs twice as long per path
@@ -506,6 +520,12 @@ k_scanline(const float *__restrict__ src, float *__restrict__ dst, const RecSrc 
 // crosses the seams: their partial minima of Lr(p-r, .) and the costs next to a neighbour's share. min() is
 // exact and commutative, so the results are the same bits as the one-wave kernel's.
 // Only for Dp == D == NPARTS*64*NVW, passes without the fused WTA.
+// Scanlines of up to this many floats per lane (D <= 64) get a ring of 8 slots instead of 16: the main loop is unrolled
+// over one round of the ring and keeps an address per slot and stream in scalar registers; 16 slots spill them
+// (450 x 375 x 64, four passes: 0.30 ms rolled, 0.33 ms unrolled with 16 slots, 0.28 ms with 8).
+#ifndef SCAN_RS8_UPTO
+#define SCAN_RS8_UPTO 1
+#endif
 template <int NVW, int NPARTS = 2, bool WTA = false> struct ScanCfgSplit {
     static constexpr int NVF = NPARTS * NVW;                          // disparities per lane over all the scanline's waves = the record's NV
     static constexpr int DATA_B = 256 * NVW;                          // this wave's half of a pixel's cost vector
@@ -514,7 +534,7 @@ template <int NVW, int NPARTS = 2, bool WTA = false> struct ScanCfgSplit {
     static constexpr int NDMA = NVW >= 4 ? NVW / 4 : NVW;
     static constexpr int NST = (NVW >= 4 ? NVW / 4 : 1) + (WTA ? 1 : 0);
     static constexpr int OPS = NDMA + 1 + NST;
-    static constexpr int RS_MEM = NVW <= 4 ? 16 : 8;
+    static constexpr int RS_MEM = (NVW <= 4 && NPARTS * NVW > SCAN_RS8_UPTO) ? 16 : 8;
     static constexpr int RS_CNT = 63 / OPS + 2;
     static constexpr int RS = (RS_MEM <= RS_CNT) ? RS_MEM : (RS_CNT >= 8 ? 8 : 4);   // a power of two (slots are masked)
     static constexpr int WAITN = (RS - 2) * OPS;
@@ -701,17 +721,19 @@ scan_split_wave(const float *__restrict__ src, float *__restrict__ dst, const Re
     // one path pixel: costs/record of this pixel in (cur, cbits, cf1); the next pixel's are fetched into
     // (nxt, nbits, nf1). FILL / NEXT: the fill RS-1 pixels ahead / the next pixel exist.
     // PATCH: the pixel may be one whose first disparities take its own d1 flag (the ends of a row).
-    auto pixel = [&](int s, uint32_t par, bool FILL, bool NEXT, bool PATCH, const float (&cur)[NV], uint32_t cbits, uint32_t cf1,
-                     float (&nxt)[NV], uint32_t &nbits, uint32_t &nf1) {
+    // FS / NS: the ring slots of the fill and of the next pixel when the caller knows them (the unrolled loop: they
+    // become immediates of the instructions), -1 to have them computed from s.
+    auto pixel = [&](int s, uint32_t par, bool FILL, bool NEXT, bool PATCH, int FS, int NS, const float (&cur)[NV], uint32_t cbits,
+                     uint32_t cf1, float (&nxt)[NV], uint32_t &nbits, uint32_t &nf1) {
         if (FILL) {
             const int t = s + RS - 1;
-            issue_fill(src_b + (ptrdiff_t)t * vstep, rec_ptr(t), (uint32_t)(t & (RS - 1)) * C::SLOT_B);
+            issue_fill(src_b + (ptrdiff_t)t * vstep, rec_ptr(t), (uint32_t)(FS >= 0 ? FS : (t & (RS - 1))) * C::SLOT_B);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::WAITN) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         if (NEXT) {
-            read_slot((uint32_t)((s + 1) & (RS - 1)) * C::SLOT_B, nxt, nbits, nf1);
+            read_slot((uint32_t)(NS >= 0 ? NS : ((s + 1) & (RS - 1))) * C::SLOT_B, nxt, nbits, nf1);
         } else {
 #pragma unroll
             for (int j = 0; j < NV; j++) nxt[j] = 0.0f;
@@ -763,12 +785,25 @@ scan_split_wave(const float *__restrict__ src, float *__restrict__ dst, const Re
     };
 
     int s = 1;
-    // main part: every fill and every next pixel exists (s + 1 + RS - 1 < LEN for the second pixel of a trip)
+    // two pixels per trip: every fill and every next pixel exists (s + 1 + RS - 1 < LEN for the second pixel)
+    auto two = [&](bool patch) {
+        pixel(s, 1u, true, true, patch, -1, -1, ca, ba, fa, cb, bb, fb);
+        pixel(s + 1, 0u, true, true, patch, -1, -1, cb, bb, fb, ca, ba, fa);
+        s += 2;
+    };
+    // RS unpatched pixels per trip, for s = 1 (mod RS): every ring offset is then known at compile time (a wave alone on
+    // its SIMD pays an issue slot for every scalar instruction of the slot arithmetic)
+    auto ring_round = [&]() {
+        unroll_pixels<0, RS>([&](auto u) {
+            constexpr int U = decltype(u)::value;
+            if constexpr (U % 2 == 0) pixel(s + U, 1u, true, true, false, U, (U + 2) & (RS - 1), ca, ba, fa, cb, bb, fb);
+            else pixel(s + U, 0u, true, true, false, U, (U + 2) & (RS - 1), cb, bb, fb, ca, ba, fa);
+        });
+        s += RS;
+    };
     if constexpr (PER_PIXEL) {
-        for (; s + RS < LEN; s += 2) {
-            pixel(s, 1u, true, true, false, ca, ba, fa, cb, bb, fb);
-            pixel(s + 1, 0u, true, true, false, cb, bb, fb, ca, ba, fa);
-        }
+        while (s + 2 * RS - 2 < LEN) ring_round();
+        while (s + RS < LEN) two(false);
     } else {
         // path pixels s_lo <= s < s_hi have every flag in the strings (rec_nfill is 0 for them): all of a column, or a
         // row without its ends
@@ -776,21 +811,14 @@ scan_split_wave(const float *__restrict__ src, float *__restrict__ dst, const Re
         if (VERT) s_lo = nf_col ? LEN : 0;
         else if (W >= 3 && forward) { s_lo = max(rec.dmin + 1, 0); s_hi = min(W - 1 + rec.dmin, W); }
         else if (W >= 3) { s_lo = max(1 - rec.dmin, 0); s_hi = min(W - 1 - rec.dmin, W); }
-        for (; s + RS < LEN && s < s_lo; s += 2) {
-            pixel(s, 1u, true, true, true, ca, ba, fa, cb, bb, fb);
-            pixel(s + 1, 0u, true, true, true, cb, bb, fb, ca, ba, fa);
-        }
-        for (; s + RS < LEN && s + 1 < s_hi; s += 2) {
-            pixel(s, 1u, true, true, false, ca, ba, fa, cb, bb, fb);
-            pixel(s + 1, 0u, true, true, false, cb, bb, fb, ca, ba, fa);
-        }
-        for (; s + RS < LEN; s += 2) {
-            pixel(s, 1u, true, true, true, ca, ba, fa, cb, bb, fb);
-            pixel(s + 1, 0u, true, true, true, cb, bb, fb, ca, ba, fa);
-        }
+        while (s + RS < LEN && s < s_lo) two(true);
+        while (s + RS < LEN && s + 1 < s_hi && (s & (RS - 1)) != 1) two(false);
+        while (s + 2 * RS - 2 < LEN && s + RS - 1 < s_hi) ring_round();
+        while (s + RS < LEN && s + 1 < s_hi) two(false);
+        while (s + RS < LEN) two(true);
     }
     for (; s < LEN; s++) {
-        pixel(s, (uint32_t)(s & 1), s + RS - 1 < LEN, s + 1 < LEN, true, ca, ba, fa, cb, bb, fb);
+        pixel(s, (uint32_t)(s & 1), s + RS - 1 < LEN, s + 1 < LEN, true, -1, -1, ca, ba, fa, cb, bb, fb);
 #pragma unroll
         for (int j = 0; j < NV; j++) ca[j] = cb[j];
         ba = bb; fa = fb;
