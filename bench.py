@@ -25,7 +25,8 @@ Extra objects on that line:
                       upload of the two images and the download of the map inside, and those two separately.
   cpu_baseline     -- the CPU oracle (a port of the reference path; the reference has no CPU-only path of its
                       own) timed on a bounded sample of the same workload on all host cores, and
-                      cpu_baseline_1thread on one core; rank 0, N = 1 only.
+                      cpu_baseline_1thread on one core; cpu_baseline_small: the same for whole 450x375x64 pairs
+                      (the small configuration); rank 0, N = 1 only.
 """
 import argparse
 import hashlib
@@ -275,6 +276,24 @@ def main():
             out["cpu_baseline_1thread"] = {"value": W * band * D * 1e-6 / cpu1_s, "unit": "Mpix*disp/s", "cores": 1, "kind": "port",
                                            "sample": "the top %d full-width rows of one %dx%dx%d pair, %.1f s on 1 thread"
                                                      % (band, W, H, D, cpu1_s)}
+            # the small configuration (a pair of Teddy's size, 64 disparities), whole frames, all cores and one
+            sw, sh, sd = 450, 375, 64
+            sl, sr = synth.pair(77, sw, sh, sd)[:2]
+            so = orc.default_option(max_disparity=sd)
+            small = {}
+            for label, nt in (("all", nthr), ("one", 1)):
+                orc.set_num_threads(nt)
+                t1 = time.perf_counter()
+                reps = 0
+                while reps < 8 and (reps == 0 or time.perf_counter() - t1 < 2.0):
+                    orc.match(sl, sr, so)
+                    reps += 1
+                small[label] = reps * sw * sh * sd * 1e-6 / (time.perf_counter() - t1)
+            orc.set_num_threads(nthr)
+            out["cpu_baseline_small"] = {"value": small["all"], "value_1thread": small["one"], "unit": "Mpix*disp/s",
+                                         "cores": nthr, "kind": "port",
+                                         "sample": "whole synthetic %dx%dx%d pairs (the size of the Middlebury 2003 configuration)"
+                                                   % (sw, sh, sd)}
         print(json.dumps(out), flush=True)
     h.close()
     if world > 1:
