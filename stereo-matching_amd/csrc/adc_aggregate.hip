@@ -605,23 +605,37 @@ __device__ __forceinline__ void desc_windows(typename VecT<VEC>::T &acc0, typena
     if (u + hn + mn + tn <= R) {
         // the run does not cross the end of the ring (three times out of four)
         const float *p = rl + u * SLOT;
-        short_span<VEC>(hd, p, hn);
-        acc0 = h1 ? zero : hd;
-        acc1 = h1 ? hd : zero;
-        p += hn * SLOT;
-        span<VEC, 2>(acc0, acc1, p, 0, mn);
+        if (hn == 0) {
+            // both windows start at the same place: up to the end of the shorter one they are one and the same chain
+            // of additions (a third to a half of all pairs: both arms stop at the same edge)
+            span<VEC, 1>(hd, hd, p, 0, mn);
+            acc0 = hd;
+            acc1 = hd;
+        } else {
+            short_span<VEC>(hd, p, hn);
+            acc0 = h1 ? zero : hd;
+            acc1 = h1 ? hd : zero;
+            p += hn * SLOT;
+            span<VEC, 2>(acc0, acc1, p, 0, mn);
+        }
         p += mn * SLOT;
         vec_t tl = t1 ? acc1 : acc0;
         short_span<VEC>(tl, p, tn);
         acc0 = t1 ? acc0 : tl;
         acc1 = t1 ? tl : acc1;
     } else {
-        range1<VEC>(hd, rl, u, hn, R);
-        acc0 = h1 ? zero : hd;
-        acc1 = h1 ? hd : zero;
         int v = u + hn;
         if (v >= R) v -= R;
-        range2<VEC>(acc0, acc1, rl, v, mn, R);
+        if (hn == 0) {
+            range1<VEC>(hd, rl, v, mn, R);
+            acc0 = hd;
+            acc1 = hd;
+        } else {
+            range1<VEC>(hd, rl, u, hn, R);
+            acc0 = h1 ? zero : hd;
+            acc1 = h1 ? hd : zero;
+            range2<VEC>(acc0, acc1, rl, v, mn, R);
+        }
         v += mn;
         if (v >= R) v -= R;
         vec_t tl = t1 ? acc1 : acc0;
