@@ -469,7 +469,12 @@ k_agg_pair(const float *__restrict__ src, float *__restrict__ dst, const uint32_
             else if (b1 < b0) range1<VEC>(acc1, rl, b1, min(e1, b0 - 1) - b1 + 1, R);
             // middle: the terms both windows hold
             const int m0 = max(b0, b1), m1 = min(e0, e1);
-            range2<VEC>(acc0, acc1, rl, m0, m1 - m0 + 1, R);
+            if (b0 == b1) {   // a common start: one chain of additions serves both windows up to the end of the shorter one
+                range1<VEC>(acc0, rl, m0, m1 - m0 + 1, R);
+                acc1 = acc0;
+            } else {
+                range2<VEC>(acc0, acc1, rl, m0, m1 - m0 + 1, R);
+            }
             // tail: the terms behind the other chain's last term
             if (e0 > e1) { const int t = max(b0, e1 + 1); range1<VEC>(acc0, rl, t, e0 - t + 1, R); }
             else if (e1 > e0) { const int t = max(b1, e0 + 1); range1<VEC>(acc1, rl, t, e1 - t + 1, R); }
