@@ -862,16 +862,24 @@ k_scanline_lean(const float *__restrict__ src, float *__restrict__ dst, const Re
 #ifndef HYB_RS
 #define HYB_RS 8
 #endif
+// The one-wave rows run the lean loop (scan_split_wave with one part: 4 passes 3.43 -> 3.40 ms at 1080 rows) when
+// its deeper ring leaves room for the launch's workgroups (69 KB of LDS each: two per CU), else scan_wave with the
+// ring of HYB_RS slots (1440 rows: 672 workgroups on 256 CUs, 7.7 ms with the lean loop against 6.5 ms).
 __global__ void __launch_bounds__(256)
 k_scanline_hybrid(const float *__restrict__ src, float *__restrict__ dst, const RecSrc rec,
-                  int W, int H, int Dp, int forward, ScanParams sp, int rows_main) {
+                  int W, int H, int Dp, int forward, ScanParams sp, int rows_main, int lean_main) {
     typedef ScanCfg<4, false, HYB_RS> C;
     extern __shared__ __align__(16) uint8_t lds_raw[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int main_wgs = rows_main >> 2;
     if ((int)blockIdx.x < main_wgs) {
-        scan_wave<4, 0, true, false, HYB_RS>(src, dst, rec, nullptr, W, H, 0, Dp, Dp, forward, sp, blockIdx.x * 4 + wave,
-                                     lds_raw + (size_t)wave * C::RS * C::SLOT_B);
+        typedef ScanCfgSplit<4, 1, false> CL;
+        if (lean_main)
+            scan_split_wave<4, 1, 0, false>(src, dst, rec, W, H, Dp, forward, sp, blockIdx.x * 4 + wave, 0,
+                                            (uint32_t)(uintptr_t)lds_raw + (uint32_t)wave * CL::RS * CL::SLOT_B, nullptr, 0);
+        else
+            scan_wave<4, 0, true, false, HYB_RS>(src, dst, rec, nullptr, W, H, 0, Dp, Dp, forward, sp, blockIdx.x * 4 + wave,
+                                                 lds_raw + (size_t)wave * C::RS * C::SLOT_B);
     } else {
         __builtin_amdgcn_s_setprio(2);   // the row's four waves wait for each other every pixel: let them go first
         scan_split_wave<1, 4, 0>(src, dst, rec, W, H, Dp, forward, sp, rows_main + ((int)blockIdx.x - main_wgs), wave,
@@ -958,9 +966,13 @@ void launch_scanline_pass(const float *src, float *dst, const Planes &p, const G
             int rows_main = std::max(simds / 4 * 3, 2 * g.H - simds / 2 * 3);
             rows_main = env_int("ADC_HYB_MAIN", rows_main);
             rows_main = std::min(std::min(rows_main, simds), g.H - 1) & ~3;
-            const size_t lds_main = (size_t)4 * C::RS * C::SLOT_B, lds_rest = scan_split_lds<1, 4>();
+            typedef ScanCfgSplit<4, 1, false> CL;
+            const int wgs = rows_main / 4 + (g.H - rows_main);
+            const int lean_main = wgs <= simds / 2 && env_int("ADC_HYB_LEAN", 1);   // two workgroups per CU
+            const size_t lds_main = lean_main ? (size_t)4 * CL::RS * CL::SLOT_B : (size_t)4 * C::RS * C::SLOT_B;
+            const size_t lds_rest = scan_split_lds<1, 4>();
             k_scanline_hybrid<<<dim3(rows_main / 4 + (g.H - rows_main)), dim3(256), std::max(lds_main, lds_rest), s>>>(
-                src, dst, rec_source(p, g, 0, forward), g.W, g.H, g.Dp, forward, sp, rows_main);
+                src, dst, rec_source(p, g, 0, forward), g.W, g.H, g.Dp, forward, sp, rows_main, lean_main);
             return;
         }
     }
