@@ -173,10 +173,12 @@ def _scan_volume_and_map_match(pkg, orc, L, R, D):
     assert same(disp, want), describe("disp_final", disp, want)
 
 
-@pytest.mark.parametrize("W,H", [(96, 1100), (33, 1500), (24, 1600)])
+@pytest.mark.parametrize("W,H", [(64, 1080), (96, 1100), (33, 1500), (24, 1600)])
 def test_more_rows_than_simds(pkg, orc, synth, W, H):
     """Tall, narrow frames with 256 disparities: horizontal passes over more rows than the chip has SIMDs take
-    the mixed launch (one wave per row + four waves per row) or, from 1.5x the SIMD count, two waves per row; the final volume must still be the oracle's bits."""
+    the mixed launch (one wave per row + four waves per row; at 1080 rows its one-wave rows run the lean loop, at
+    1100 the general one) or, from 1.5x the SIMD count, two waves per row; the final volume must still be the
+    oracle's bits."""
     L, R, _ = synth.pair(81, 256, H, 256)
     _scan_volume_and_map_match(pkg, orc, np.ascontiguousarray(L[:, :W]), np.ascontiguousarray(R[:, :W]), 256)
 
