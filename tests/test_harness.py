@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import DATA, GOLDEN, load_bgr, load_gray
+from conftest import DATA, GOLDEN, ROOT, load_bgr, load_gray
 
 
 @pytest.fixture(scope="module")
@@ -177,3 +177,18 @@ def test_cli_2021_scene_pfm_eval_and_depth(pkg, horc, tmp_path):
     _, o_u8, o_lo, o_hi = horc.depth(disp, f, b, doffs)
     assert np.array_equal(load_gray(depth_png), o_u8)
     assert "max_depth%g" % o_hi in p.stdout and "min_depth%g" % o_lo in p.stdout
+
+
+@pytest.mark.gpu
+def test_c_abi_under_host_sanitizers():
+    """The library built with AddressSanitizer + UBSan on its host code (`make -C stereo-matching_amd san`), driven
+    through every C-ABI entry point by tests/cpp/host_san_driver.cpp: no report, exit code 0."""
+    exe = os.path.join(ROOT, "stereo-matching_amd", "bin", "host_san_driver")
+    if not os.path.exists(exe):
+        pytest.skip("bin/host_san_driver not built (make -C stereo-matching_amd san)")
+    env = dict(os.environ, ASAN_OPTIONS="protect_shadow_gap=0:detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1")
+    p = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=240)
+    out = p.stdout + p.stderr
+    assert p.returncode == 0, out[-3000:]
+    assert "host sanitizer driver ok" in p.stdout
+    assert "AddressSanitizer" not in out and "runtime error" not in out, out[-3000:]
