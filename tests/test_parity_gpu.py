@@ -121,6 +121,19 @@ def test_disparity_counts(pkg, orc, synth, D):
     check_against_oracle(pkg, orc, L, R, max_disparity=D)
 
 
+@pytest.mark.parametrize("W,H,dmin,dmax", [(10, 9, -5, 251), (3, 5, 0, 256), (2, 4, -3, 253), (70, 20, 7, 263),
+                                           (130, 12, -40, 216), (40, 11, -5, 195), (300, 7, 250, 506), (9, 6, -300, -44)])
+def test_flag_strings_at_row_ends(pkg, orc, W, H, dmin, dmax):
+    """More than 128 disparities: the scanline passes take their colour-step flags from the shifted row strings and
+    patch the disparities whose flag is the pixel's own. Narrow frames and shifted disparity ranges make that most
+    or all of a row (no usable right-image column at all, ranges far off the image on either side)."""
+    rng = np.random.default_rng(1000 + W)
+    L = rng.integers(0, 256, size=(H, W, 3)).astype(np.uint8)
+    R = np.roll(L, -3, axis=1)
+    R[::2] = rng.integers(0, 256, size=R[::2].shape).astype(np.uint8)
+    check_against_oracle(pkg, orc, L, R, min_disparity=dmin, max_disparity=dmax)
+
+
 def test_tiny_images(pkg, orc):
     rng = np.random.default_rng(5)
     for (H, W) in [(1, 1), (1, 7), (9, 1), (2, 2), (5, 3)]:
