@@ -134,6 +134,31 @@ def test_flag_strings_at_row_ends(pkg, orc, W, H, dmin, dmax):
     check_against_oracle(pkg, orc, L, R, min_disparity=dmin, max_disparity=dmax)
 
 
+@pytest.mark.parametrize("seed", list(range(40)))
+def test_random_configurations(pkg, orc, seed):
+    """Seeded random frame sizes, disparity ranges and options (arm lengths and thresholds, penalties, refinement
+    switches): every tap against the oracle."""
+    rng = np.random.default_rng(7000 + seed)
+    W, H = int(rng.integers(1, 180)), int(rng.integers(1, 120))
+    D = int(rng.choice([1, 2, 5, 17, 64, 65, 100, 128, 129, 200, 256, 300]))
+    dmin = int(rng.integers(-12, 13))
+    L1 = int(rng.integers(1, 45))
+    opt = dict(min_disparity=dmin, max_disparity=dmin + D, cross_L1=L1, cross_L2=int(rng.integers(1, L1 + 1)),
+               cross_t1=int(rng.integers(5, 40)), cross_t2=int(rng.integers(2, 20)),
+               so_p1=float(rng.uniform(0.2, 2.0)), so_p2=float(rng.uniform(1.0, 4.0)), so_tso=int(rng.integers(5, 30)),
+               lrcheck_thres=float(rng.uniform(0.5, 2.0)), irv_ts=int(rng.integers(5, 40)), irv_th=float(rng.uniform(0.2, 0.6)),
+               do_lr_check=bool(rng.integers(0, 2)), do_filling=bool(rng.integers(0, 2)),
+               do_discontinuity_adjustment=bool(rng.integers(0, 2)))
+    L = rng.integers(0, 256, size=(H, W, 3)).astype(np.uint8)
+    # smooth the texture along x so that arms have room to grow, and shift it for the right view
+    k = int(rng.integers(1, 9))
+    L = (np.cumsum(np.pad(L.astype(np.int32), ((0, 0), (k, 0), (0, 0)), mode="edge"), axis=1)[:, k:] -
+         np.cumsum(np.pad(L.astype(np.int32), ((0, 0), (k, 0), (0, 0)), mode="edge"), axis=1)[:, :-k]) // k
+    L = np.ascontiguousarray(L.astype(np.uint8))
+    R = np.ascontiguousarray(np.roll(L, -int(rng.integers(0, 9)), axis=1))
+    check_against_oracle(pkg, orc, L, R, **opt)
+
+
 def test_tiny_images(pkg, orc):
     rng = np.random.default_rng(5)
     for (H, W) in [(1, 1), (1, 7), (9, 1), (2, 2), (5, 3)]:
