@@ -22,11 +22,16 @@ Extra objects on that line:
   roofline_kernels -- the same accounting for every volume kernel of a match, launch by launch.
   aggregation_stage-- all aggregation launches together against the model's 32 B (+4 B for the cost volume).
   t_match          -- the host-pointer boundary (adc_match) on pinned host images: wall time per frame with the
-                      upload of the two images and the download of the map inside, and those two separately.
+                      upload of the two images and the download of the map inside, and those two separately;
+                      value_pcie is its rate (the reference's own `speed` includes everything, ADC/main.cpp:221-230).
+  batch_256        -- adc_match_batch over 256 host-resident pairs (8 distinct ones) on this rank's initialised handle:
+                      the reference's dataset loop (ADC/main.cpp:62-255) with uploads, matches and downloads of
+                      neighbouring pairs overlapped; every rank runs it on its own GPU, the rate is the sum over ranks.
+  c4               -- one synthetic 3840x2160 pair with 512 disparities (two 17 GB volumes), rank 0 at N = 1 only.
   cpu_baseline     -- the CPU oracle (a port of the reference path; the reference has no CPU-only path of its
                       own) timed on a bounded sample of the same workload on all host cores, and
-                      cpu_baseline_1thread on one core; cpu_baseline_small: the same for whole 450x375x64 pairs
-                      (the small configuration); rank 0, N = 1 only.
+                      cpu_baseline_1thread on one core; cpu_baseline_small_synthetic: the same for whole synthetic
+                      450x375x64 pairs (the small configuration's size); rank 0, N = 1 only.
 """
 import argparse
 import hashlib
@@ -56,6 +61,38 @@ def kernel_source_stamp():
     return h.hexdigest()[:16]
 
 
+def c4_leg(pkg, synth, torch, dev, device_index):
+    """One synthetic 3840x2160 pair, 512 disparities (two 17 GB volumes resident in HBM): ms per Match with the inputs
+    on the device, the stage and volume-kernel times of a profiled Match, and the rate against the byte model."""
+    W, H, D = 3840, 2160, 512
+    L, R = synth.pair(2026, W, H, D)[:2]
+    dl, dr = torch.from_numpy(L).to(dev), torch.from_numpy(R).to(dev)
+    do = torch.empty((H, W), dtype=torch.float32, device=dev)
+    h = pkg.ADCensusStereo(device_index)
+    if not h.Initialize(W, H, pkg.ADCensusOption(max_disparity=D)):
+        raise SystemExit("c4: Initialize failed: " + h.last_error())
+    stream = torch.cuda.current_stream().cuda_stream
+    h.match_device(dl.data_ptr(), dr.data_ptr(), do.data_ptr(), stream)
+    torch.cuda.synchronize()
+    n = 3
+    t0 = time.perf_counter()
+    for _ in range(n):
+        h.match_device(dl.data_ptr(), dr.data_ptr(), do.data_ptr(), stream)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    h.set_profiling(True)
+    h.match_device(dl.data_ptr(), dr.data_ptr(), do.data_ptr(), stream)
+    torch.cuda.synchronize()
+    res = {"workload": "synthetic 3840x2160 pair (seed 2026), 512 disparities, full Match, inputs resident in HBM",
+           "ms_per_frame": ms, "value": W * H * D * 1e-6 / (ms * 1e-3), "unit": "Mpix*disp/s",
+           "whole_match_roofline_frac": (72.0 * W * H * D + 120.0 * W * H) / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9),
+           "stage_ms": {k: round(v, 3) for k, v in h.stage_times().items()},
+           "kernel_ms": {k: round(v, 3) for k, v in h.kernel_times().items()},
+           "valid_fraction": float(torch.isfinite(do).float().mean().item())}
+    h.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -65,15 +102,27 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--disp", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch-pairs", type=int, default=256, help="pairs of the host-fed batch leg (0 = skip it)")
+    ap.add_argument("--no-c4", action="store_true", help="skip the 3840x2160x512 leg")
+    ap.add_argument("--quick", action="store_true", help="the resident-input steps and the per-kernel times only "
+                    "(no CPU baseline, no batch leg, no 3840x2160x512 leg): what the A/B and profiling tools run")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank rehearsal on a one-GPU box: gloo backend, every rank on device 0")
     args = ap.parse_args()
+    if args.quick:
+        args.no_cpu_baseline, args.no_c4, args.batch_pairs = True, True, 0
 
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         # no launcher: start one rank per GPU ourselves, before this process initialises any GPU state
+        port = os.environ.get("MASTER_PORT")
+        if not port:                       # any free port of this host
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = str(sk.getsockname()[1])
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29511"),
+               "--master-addr", "127.0.0.1", "--master-port", port,
                os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.run(cmd).returncode)
     world = int(env_world or "1")
@@ -143,22 +192,42 @@ def main():
         pin_l, pin_r = torch.from_numpy(pairs[0][0]).pin_memory(), torch.from_numpy(pairs[0][1]).pin_memory()
         pin_o = torch.empty((H, W), dtype=torch.float32).pin_memory()
         nl, nr, no = pin_l.numpy(), pin_r.numpy(), pin_o.numpy()
-        h.set_profiling(True)
         for _ in range(2):
             assert h.Match(nl, nr, no), h.last_error()
-        nrep, h2d, d2h = 5, 0.0, 0.0
+        nrep, h2d, d2h = 10, 0.0, 0.0
         t0 = time.perf_counter()
-        for _ in range(nrep):
+        for _ in range(nrep):                  # the wall time: no events between the kernels
+            assert h.Match(nl, nr, no), h.last_error()
+        wall = (time.perf_counter() - t0) / nrep * 1e3
+        h.set_profiling(True)                  # the two transfers on their own, from profiled calls
+        for _ in range(3):
             assert h.Match(nl, nr, no), h.last_error()
             x = h.transfer_times()
-            h2d += x["h2d"] / nrep
-            d2h += x["d2h"] / nrep
-        wall = (time.perf_counter() - t0) / nrep * 1e3
+            h2d += x["h2d"] / 3
+            d2h += x["d2h"] / 3
         h.set_profiling(False)
         t_match = {"ms_per_frame": wall, "h2d_ms": h2d, "d2h_ms": d2h, "value": W * H * D * 1e-6 / (wall * 1e-3),
                    "unit": "Mpix*disp/s", "bytes_in": 2 * 3 * W * H, "bytes_out": 4 * W * H,
                    "note": "adc_match, images and map in pinned host memory, one frame at a time (upload, match, "
                            "download one after the other); PCIe-inclusive, never the headline value"}
+
+    # the host-fed batch: adc_match_batch over pairs in ordinary host memory on this rank's handle (every rank)
+    batch_leg = None
+    if args.batch_pairs > 0:
+        n_distinct = 8
+        bp = [pairs[i] if i < 2 else synth.pair(2000 + n_distinct * rank + i, W, H, D)[:2] for i in range(n_distinct)]
+        outs = [np.empty((H, W), np.float32) for _ in range(n_distinct)]
+        n = args.batch_pairs
+        lefts, rights, dst = [bp[i % n_distinct][0] for i in range(n)], [bp[i % n_distinct][1] for i in range(n)], [outs[i % n_distinct] for i in range(n)]
+        opt = pkg.ADCensusOption(max_disparity=D)
+        pkg.match_batch(lefts[:4], rights[:4], opt, [local_rank], handles=[h], out=dst[:4])      # second staging set allocated
+        b_elapsed = batch.timed_steps(lambda i: pkg.match_batch(lefts, rights, opt, [local_rank], handles=[h], out=dst), 1, 0,
+                                      torch.cuda.synchronize, dist if world > 1 else None, None if args.rehearse else dev)
+        batch_leg = {"pairs_per_gpu": n, "distinct_pairs": n_distinct, "n_gpus": world, "seconds": b_elapsed,
+                     "ms_per_frame": b_elapsed / n * 1e3, "pairs_per_s": world * n / b_elapsed,
+                     "value": world * n * W * H * D * 1e-6 / b_elapsed, "unit": "Mpix*disp/s",
+                     "note": "adc_match_batch on caller handles, pairs in pageable host memory: host copy into pinned staging, "
+                             "upload, match and download of neighbouring pairs overlap (three streams per GPU)"}
 
     vol = float(W) * H * D                     # pixel*disparities per launch of a volume kernel
 
@@ -225,6 +294,7 @@ def main():
         out = {
             "metric": "Mpix*disp/s",
             "value": batch.throughput(world, args.steps, W, H, D, elapsed),
+            "value_pcie": t_match["value"] if t_match else None,
             "unit": "Mpix*disp/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -250,7 +320,10 @@ def main():
             "aggregation_stage": aggr_stage,
             "roofline_kernels": per_kernel,
             "t_match": t_match,
+            "batch_256": batch_leg,
         }
+        if batch_leg:
+            batch_leg["efficiency_vs_resident"] = ms_per_frame / batch_leg["ms_per_frame"]
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as orc          # reported baseline only; never on the measured path
             nthr = orc.num_threads()
@@ -290,10 +363,13 @@ def main():
                     reps += 1
                 small[label] = reps * sw * sh * sd * 1e-6 / (time.perf_counter() - t1)
             orc.set_num_threads(nthr)
-            out["cpu_baseline_small"] = {"value": small["all"], "value_1thread": small["one"], "unit": "Mpix*disp/s",
+            out["cpu_baseline_small_synthetic"] = {"value": small["all"], "value_1thread": small["one"], "unit": "Mpix*disp/s",
                                          "cores": nthr, "kind": "port",
                                          "sample": "whole synthetic %dx%dx%d pairs (the size of the Middlebury 2003 configuration)"
                                                    % (sw, sh, sd)}
+        if world == 1 and not args.no_c4:
+            h.close()                               # its volumes make room
+            out["c4"] = c4_leg(pkg, synth, torch, dev, local_rank)
         print(json.dumps(out), flush=True)
     h.close()
     if world > 1:

@@ -113,7 +113,9 @@ typedef enum adc_kernel_id {
                                 that runs two passes (1+2, 3+4, 5+6) reports its time under the first of them and
                                 leaves the second at 0 ms */
     ADC_KERNEL_SCAN0 = 9,    /* scanline passes 0..3: ids 9..12 (left-right, right-left, up-down, down-up)     */
-    ADC_KERNEL_WTA_RIGHT = 13,
+    ADC_KERNEL_WTA_RIGHT = 13, /* right-view WTA; on small frames, where the left-view WTA is a kernel of its own instead
+                                of a part of the last scanline pass, that kernel too. (With the debug taps on, the
+                                copy of the aggregated volume falls into SCAN0's interval: time with taps off.) */
     ADC_KERNEL_COUNT_ = 14
 } adc_kernel_id;
 
@@ -161,8 +163,8 @@ int adc_stage_times(adc_handle *h, float *ms, int n);
  * indexed by adc_kernel_id. For per-kernel roofline accounting. */
 int adc_kernel_times(adc_handle *h, float *ms, int n);
 
-/* Number of launches of the dominant aggregation kernel in one match and the device time of the
- * last profiled match spent in them (the sum of their adc_kernel_times entries). */
+/* Number of aggregation launches of the last match (5 when same-axis passes share a launch, else 8) and the
+ * device time of the last profiled match spent in them (the sum of their adc_kernel_times entries). */
 int adc_aggr_kernel_stats(adc_handle *h, int *launches, float *total_ms);
 
 /* What the last profiled adc_match spent around the pipeline, in ms: ms[0] host copy of the two images into
@@ -199,9 +201,8 @@ typedef struct adc_batch_desc {
 } adc_batch_desc;
 int adc_match_batch(const adc_batch_desc *desc);
 
-/* adc_match_device for callers that cannot allocate (code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc). It has no counterpart in the reference. It takes no handle and calls no
- * hipMalloc, hipFree, stream/event creation or any other allocating routine: every intermediate buffer of the
+/* adc_match_device for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc). It has no counterpart in the reference. It takes no handle and calls no
+ * hipMalloc, hipFree or stream/event creation: every intermediate buffer of the
  * pipeline (both cost volumes, the 2-D planes, lists, tables) is laid out in one static device array of
  * ADC_STATIC_SCRATCH_BYTES that each GPU the library runs on holds until the process ends. The caller passes the
  * frame size and option with every call plus the device-resident inputs and output, exactly as to
@@ -209,7 +210,11 @@ int adc_match_batch(const adc_batch_desc *desc);
  * array (about 700 bytes per pixel at 64 disparities; every 450x375x64 Middlebury 2003 pair fits) are rejected
  * with ADC_ERR_UNSUPPORTED and a message naming the limit. The work is enqueued on `stream` (a hipStream_t;
  * NULL = the null stream); a call whose size or option differs from the previous call on that GPU first
- * re-lays the array out, uploads the option's tables and waits for the stream once, later calls only enqueue.
+ * re-lays the array out, sets kernel attributes, uploads the option's tables from pageable host memory (the
+ * runtime may stage that copy in memory of its own) and waits for the stream once; later calls only enqueue
+ * kernels, device-to-device copies and memsets. It is not for streams under graph capture: on a capturing stream
+ * the call enqueues nothing, leaves the capture intact and returns ADC_ERR_UNSUPPORTED (a replayed graph would
+ * carry the captured frame's set-up and voting state).
  * All calls on one GPU share that GPU's array, which keeps the previous call's contents (what must start at
  * zero is cleared by the call): calls that overlap on one GPU, from any threads or streams, race.
  * Errors: as adc_match_device; the message is read with adc_last_error(NULL) in the calling thread. */

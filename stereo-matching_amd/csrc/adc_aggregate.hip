@@ -26,7 +26,6 @@
 #include "adc_common.h"
 
 #include <algorithm>
-#include <cstdlib>
 
 namespace adc {
 
@@ -601,6 +600,9 @@ __device__ __forceinline__ void desc_windows(typename VecT<VEC>::T &acc0, typena
 #ifdef AGG_DIAG_ONE_TERM   // diagnostic: every window is one term (what is left is the kernel's memory skeleton)
     d = (d & 0x80000000u) | (1u << 14);
 #endif
+#ifdef AGG_DIAG_UNIFORM    // diagnostic: every pair has the same windows (1 + 28 + 1 terms, the frame's mean): no imbalance between waves
+    d = 0x80000000u | 14u | (1u << 7) | (28u << 14) | (1u << 22) | (1u << 30);
+#endif
     const int hn = (d >> 7) & 127, mn = (d >> 14) & 255, tn = (d >> 22) & 127;
     const bool h1 = (d >> 29) & 1, t1 = (d >> 30) & 1;
     int u = q - (int)(d & 127);
@@ -657,7 +659,19 @@ __device__ unsigned long long g_agg_stamp[8];
 #else
 #define STAMP(i)
 #endif
-template <int VEC, bool FULLD>
+// MODE: how ring 1 is filled when a slot is a full 128 floats (FULLD, VEC = 2; other shapes always use mode 0).
+//   0  every wave brings its own pair of positions by one 16-byte-per-lane LDS-DMA per iteration
+//   1  a loader wave: wave 15 issues the fills of all pairs and the descriptor DMA, waves 0..14 only compute
+//      (30 positions per iteration) and never touch the vector-memory wait counter
+//   2  every wave loads its pair into registers (global_load_dwordx4) and writes it to the ring one iteration later
+template <int VEC, bool FULLD, int MODE> struct FusedShape {
+    static constexpr bool X4 = FULLD && VEC == 2;
+    static constexpr bool LOADER = X4 && MODE == 1;
+    static constexpr bool REGFILL = X4 && MODE == 2;
+    static constexpr int CW = LOADER ? AGG_WAVES - 1 : AGG_WAVES;   // computing waves
+    static constexpr int B = 2 * CW;                                 // positions per iteration
+};
+template <int VEC, bool FULLD, int MODE>
 __global__ void __launch_bounds__(AGG_WAVES * 64)
 k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 *__restrict__ desc,
             int W, int H, int Dp, int vertical, int cap, int R1, int R2, int dpad) {
@@ -667,7 +681,9 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
     typedef typename VecT<VEC>::T vec_t;
     typedef volatile vec_t __attribute__((address_space(3))) *lds_vec_ptr;
     constexpr int SLOT = 64 * VEC;
-    constexpr int B = PAIR_B;
+    typedef FusedShape<VEC, FULLD, MODE> Shape;
+    constexpr int B = Shape::B, CW = Shape::CW;
+    constexpr bool LOADER = Shape::LOADER, REGFILL = Shape::REGFILL;
     extern __shared__ __align__(16) float ring[];   // ring 1 (src): R1 x SLOT, then ring 2 (A): R2 x SLOT
     float *const ring2 = ring + (size_t)R1 * SLOT;
     const int lane = threadIdx.x & 63;
@@ -722,14 +738,14 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
     const float *fill_p = fsrc + (ptrdiff_t)fp * mstride;
     // (full 128-float slots: ONE 16-byte-per-lane DMA fills both slots of the pair, lanes 0..31 the first position,
     //  lanes 32..63 the second -- issuing a fill instruction costs a wave hundreds of cycles, whatever its width)
-    constexpr bool FILL_X4 = FULLD && VEC == 2;
+    constexpr bool FILL_X4 = Shape::X4;
     constexpr int NFILL = FILL_X4 ? 1 : 2 * VEC;   // fill instructions per wave and iteration
     const float *fill_p4 = src + lbase + (lane & 31) * 4 + (ptrdiff_t)fp * mstride;
     const ptrdiff_t second = (lane >> 5) ? (ptrdiff_t)mstride : (ptrdiff_t)0;
     float *out_p = dst + lbase + lane * VEC + (ptrdiff_t)(2 * wave - B * nlead) * mstride;   // (stored to inside the line only)
     // The workgroup's pair descriptors travel like the fills: by LDS-DMA, two iterations ahead of their use, into a
     // small staging area behind the rings (three 512-byte buffers used in turn: one being read, one landed, one in
-    // flight). ONE instruction of wave 0 moves
+    // flight). ONE instruction of one wave (wave 0, or the loader wave) moves
     // them all: lanes 0..15 bring the stage-1 records of the 16 waves (consecutive pairs: 256 contiguous bytes),
     // lanes 16..31 the stage-2 records. It is issued in front of that wave's fill, so the wait for the fill
     // covers it, and the barrier that publishes the fills publishes the descriptors; behind that barrier every wave
@@ -738,6 +754,7 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
     // for a ring read would sit out the whole scalar load. Ordinary vector loads would make the compiler wait for
     // every fill in flight in front of their first use. (An LDS-DMA instruction costs the CU some tens of cycles
     // whatever it moves, and all waves of the CU queue for that: one per wave and iteration doubled the queue.)
+    constexpr int DW = LOADER ? CW : 0;            // the wave that brings the descriptors
     const size_t drow = (size_t)line * (((LEN + 1) >> 1) + 2 * dpad) + dpad;
     const uint4 *d1p = desc + drow + (pa >> 1);                    // stage-1 pairs of the first iteration
     const uint4 *d2p = desc + drow - (B * nlead) / 2;              // stage-2 pairs of the first iteration
@@ -745,7 +762,7 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
     float *const stage = ring2 + (size_t)R2 * SLOT;                // three buffers of 128 dwords
     const uint32_t stage_off = (uint32_t)(uintptr_t)stage + (uint32_t)wave * 16u;
     auto desc_dma = [&](int it_ahead, int buf) {   // the descriptors `it_ahead` iterations ahead of dsrc into buffer `buf`
-        if (wave == 0 && lane < 32)
+        if (wave == DW && lane < 32)
             __builtin_amdgcn_global_load_lds(dsrc + (ptrdiff_t)it_ahead * (B / 2),
                                              (__attribute__((address_space(3))) void *)(stage + buf * 128), 16, 0, 0);
     };
@@ -763,12 +780,49 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
     desc_dma(1, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+
+    if constexpr (LOADER) {
+        if (wave == CW) {
+            // The loader wave: per iteration the descriptor DMA and the fills of all CW pairs (positions fl + 2w,
+            // fl + 2w + 1 into slots ql + 2w, ql + 2w + 1), then the wait for the PREVIOUS iteration's (everything but
+            // the 1 + CW operations just issued), then the barrier that publishes them. Pairs behind the end of the
+            // line are skipped; from then on the wait is for everything.
+            int fl = pa + 2 * B + cap;             // > 0
+            int ql = 2 * cap + 2 * B;              // < R1
+            int sbl = 2;
+            const float *lsrc = src + lbase + (lane & 31) * 4;
+            const int hi = lane >> 5;
+            for (int o0 = -B * nlead; o0 < LEN; o0 += B) {
+                desc_dma(2, sbl);
+                for (int w = 0; w < CW; w++) {
+                    const int p = fl + 2 * w;
+                    if (p < LEN) {
+                        int q = ql + 2 * w;
+                        if (q >= R1) q -= R1;
+                        const int pl = min(p + hi, LEN - 1);   // a lone last position: its second half re-reads it
+                        ring_fill_x4(lsrc + (ptrdiff_t)pl * mstride, ring + q * SLOT);
+                    }
+                }
+                if (fl + B <= LEN) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 + CW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                fl += B;
+                ql += B; if (ql >= R1) ql -= R1;
+                sbl = sbl == 2 ? 0 : sbl + 1;      // (the order the computing waves read them in)
+                dsrc += B / 2;
+            }
+            return;
+        }
+    }
+
     u32x4 d1v;
     uint32_t d2v;
     read_slot(0, d1v, d2v);
     uint4 d1c = make_uint4(uni(d1v.x), uni(d1v.y), uni(d1v.z), 0u);
     uint32_t d2c = uni(d2v);
     int nstore_prev = 0, sb = 0, sb2 = 2;         // staging buffers: sb holds this iteration's descriptors, sb2 takes the DMA
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 freg = {};                               // REGFILL: this iteration's pair on its way to the ring
 
 #ifdef AGG_STAMP
     unsigned long long st[8] = {}, tprev = __builtin_readcyclecounter();
@@ -778,8 +832,8 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
         //     (Issuing the fills of half the waves between the stages instead, so that their queueing for the CU's
         //     DMA path overlaps the other half's sums, moved time between the phases of an iteration and left its
         //     length as it was.)
-        desc_dma(2, sb2);
-        {
+        if constexpr (!LOADER) {
+            desc_dma(2, sb2);
             const float *p1 = fill_p + (fp + 1 < LEN ? (ptrdiff_t)mstride : (ptrdiff_t)0);
             __builtin_amdgcn_s_setprio(3);
 #ifdef AGG_DIAG_NO_MEM   // diagnostic: the fill reads one and the same line (cache hits), the stores are dropped
@@ -787,7 +841,9 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
                 ring_fill_x4(src + lbase + (lane & 31) * 4, ring + qf * SLOT);
             } else
 #endif
-            if constexpr (FILL_X4) {
+            if constexpr (REGFILL) {
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(freg) : "v"(fill_p4 + (fp + 1 < LEN ? second : (ptrdiff_t)0)) : "memory");
+            } else if constexpr (FILL_X4) {
                 ring_fill_x4(fill_p4 + (fp + 1 < LEN ? second : (ptrdiff_t)0), ring + qf * SLOT);
             } else {
 #pragma unroll
@@ -813,27 +869,35 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
         STAMP(1)
         // (c) stage 2: outputs o, o + 1 from ring 2 (written before the previous barrier)
         int nstore = 0;
+        vec_t out0 = {}, out1 = {};
         if (d2c) {
-            vec_t acc0, acc1;
-            desc_windows<VEC>(acc0, acc1, rl2, R2, q2, d2c);
-            const bool two = d2c >> 31;
-#ifdef AGG_DIAG_NO_MEM
-            if (reinterpret_cast<float &>(acc0) == -1.f) *reinterpret_cast<vec_t *>(out_p) = acc0 + acc1;   // (never true)
-            nstore = 0;
-#else
-            if (kok) {
-                *reinterpret_cast<vec_t *>(out_p) = acc0;
-                if (two) *reinterpret_cast<vec_t *>(out_p + mstride) = acc1;
-            }
-            nstore = two ? 2 : 1;
-#endif
+            desc_windows<VEC>(out0, out1, rl2, R2, q2, d2c);
+            nstore = (d2c >> 31) ? 2 : 1;
         }
+        if constexpr (REGFILL) {
+            // the pair loaded at the top of the iteration goes into the ring in front of the stores: the wait is then
+            // for that load (and older operations) only
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(freg) : : "memory");
+            typedef volatile f32x4 __attribute__((address_space(3))) *lds_f4_ptr;
+            *(lds_f4_ptr)(uintptr_t)(ring + qf * SLOT + lane * 4) = freg;
+        }
+#ifdef AGG_DIAG_NO_MEM
+        if (nstore && reinterpret_cast<float &>(out0) == -1.f) *reinterpret_cast<vec_t *>(out_p) = out0 + out1;   // (never true)
+        nstore = 0;
+#else
+        if (nstore && kok) {
+            *reinterpret_cast<vec_t *>(out_p) = out0;
+            if (nstore == 2) *reinterpret_cast<vec_t *>(out_p + mstride) = out1;
+        }
+#endif
         STAMP(2)
         // (d) the fills of the PREVIOUS iteration must have landed before the next iteration reads them (and with
         //     them the descriptors issued in front of them, which are the next iteration's). Issued since then, in
         //     order: that iteration's stores, this one's descriptor DMA, its fills and its stores -- 2 + 1 + NFILL + 2
         //     operations in the steady state, and never fewer than 1 + NFILL (wave 0; the others issue no descriptor DMA).
-        if constexpr (FULLD) {
+        if constexpr (LOADER || REGFILL) {
+            // (nothing to wait for: the loader wave waits for its fills / the ring write above followed its own wait)
+        } else if constexpr (FULLD) {
             if (wave == 0) {
                 if (nstore == 2 && nstore_prev == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 + NFILL) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 + NFILL) : "memory");
@@ -851,7 +915,7 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
         STAMP(4)
         sb2 = sb;
         sb = sb == 2 ? 0 : sb + 1;
-        read_slot(sb, d1v, d2v);                             // the next iteration's descriptors (wave 0 brought them)
+        read_slot(sb, d1v, d2v);                             // the next iteration's descriptors (wave DW brought them)
         q1 += B; if (q1 >= R1) q1 -= R1;
         qf += B; if (qf >= R1) qf -= R1;
         qw += B; if (qw >= R2) qw -= R2;
@@ -996,8 +1060,12 @@ static hipError_t setup_vec() {
     ADC_PAIR_ATTR(true, false, true); ADC_PAIR_ATTR(false, false, true); ADC_PAIR_ATTR(false, true, true);
     ADC_PAIR_ATTR(true, false, false); ADC_PAIR_ATTR(false, false, false); ADC_PAIR_ATTR(false, true, false);
 #undef ADC_PAIR_ATTR
-    set(reinterpret_cast<const void *>(&k_agg_fused<VEC, true>), 160 * 1024);
-    set(reinterpret_cast<const void *>(&k_agg_fused<VEC, false>), 160 * 1024);
+    set(reinterpret_cast<const void *>(&k_agg_fused<VEC, true, 0>), 160 * 1024);
+    set(reinterpret_cast<const void *>(&k_agg_fused<VEC, false, 0>), 160 * 1024);
+    if (VEC == 2) {
+        set(reinterpret_cast<const void *>(&k_agg_fused<2, true, 1>), 160 * 1024);
+        set(reinterpret_cast<const void *>(&k_agg_fused<2, true, 2>), 160 * 1024);
+    }
     return e;
 }
 hipError_t aggregate_setup_device() {
@@ -1012,9 +1080,8 @@ static bool pair_kernel_ok(const Geom &g, int max_arm);
 // workgroups to fill the chip (a segment's lead-in recomputes 2*cap + B stage-1 positions).
 bool aggregate_pair_fusion_supported(const Geom &g, int max_arm) {
     // Measured from 320 x 240 x 64 to 3840 x 2160 x 512: the fused launches win at every size (3 % of the
-    // aggregation stage at the small end, 12-20 % from 640 x 480 up). ADC_AGG_FUSE=0 (test hook) turns them off.
-    const char *str = std::getenv("ADC_AGG_FUSE");
-    const int env = str ? std::atoi(str) : 1;
+    // aggregation stage at the small end, 12-20 % from 640 x 480 up). Tuning::agg_fuse = 0 (test hook) turns them off.
+    const int env = g.tune.agg_fuse;
     const int vec = (g.Dp >= 128 && g.Dp % 2 == 0) ? 2 : 1;
     const size_t lds = (size_t)(4 * ((max_arm + 1) & ~1) + 5 * PAIR_B) * 64 * vec * 4 + 3 * 512;
     return env && pair_kernel_ok(g, max_arm) && lds <= 160 * 1024;
@@ -1028,18 +1095,24 @@ void launch_aggregate_fused_pair(const float *src, float *dst, const uint4 *desc
     const int chunks = (g.Dp + SLOT - 1) / SLOT;
     const int lines = vertical ? g.W : g.H;
     const int cap = (max_arm + 1) & ~1;                      // even (see the kernel)
-    const int R1 = 2 * cap + 3 * PAIR_B, R2 = 2 * cap + 2 * PAIR_B;
+    const bool fulld = g.Dp % SLOT == 0;
+    const int mode = (vec == 2 && fulld) ? g.tune.agg_mode : 0;
+    const int B = mode == 1 ? FusedShape<2, true, 1>::B : PAIR_B;
+    const int R1 = 2 * cap + 3 * B, R2 = 2 * cap + 2 * B;
     const size_t lds = (size_t)(R1 + R2) * SLOT * sizeof(float) + 3 * 512;   // + the descriptor staging buffers
     dim3 grid(chunks, lines), block(AGG_WAVES * 64);
-    const bool fulld = g.Dp % SLOT == 0;
-#define ADC_FUSED_GO(V_, F_) k_agg_fused<V_, F_><<<grid, block, lds, s>>>(src, dst, desc, g.W, g.H, g.Dp, vertical, cap, R1, R2, pair_desc_pad(max_arm))
-    if (vec == 2) { if (fulld) ADC_FUSED_GO(2, true); else ADC_FUSED_GO(2, false); }
-    else { if (fulld) ADC_FUSED_GO(1, true); else ADC_FUSED_GO(1, false); }
+#define ADC_FUSED_GO(V_, F_, M_) k_agg_fused<V_, F_, M_><<<grid, block, lds, s>>>(src, dst, desc, g.W, g.H, g.Dp, vertical, cap, R1, R2, pair_desc_pad(max_arm))
+    if (vec == 2) {
+        if (!fulld) ADC_FUSED_GO(2, false, 0);
+        else if (mode == 1) ADC_FUSED_GO(2, true, 1);
+        else if (mode == 2) ADC_FUSED_GO(2, true, 2);
+        else ADC_FUSED_GO(2, true, 0);
+    } else { if (fulld) ADC_FUSED_GO(1, true, 0); else ADC_FUSED_GO(1, false, 0); }
 #undef ADC_FUSED_GO
 }
 
 static bool pair_kernel_ok(const Geom &g, int max_arm) {
-    static const int pair_env = std::getenv("ADC_AGG_PAIR") ? std::atoi(std::getenv("ADC_AGG_PAIR")) : 1;
+    const int pair_env = g.tune.agg_pair;
     const int vec = (g.Dp >= 128 && g.Dp % 2 == 0) ? 2 : 1;
     // div_by_count needs a count in [1, 2^14]: the 16-bit support counts (wrap-around, as the reference's
     // vec_sup_count_) stay below 2^14 while (2*cap+1)^2 does, i.e. for arm caps up to 63; longer arms take the
@@ -1051,7 +1124,7 @@ static bool pair_kernel_ok(const Geom &g, int max_arm) {
 
 // The first aggregation pass (horizontal, no division) with the initial costs computed inside it.
 bool aggregate_cost_fusion_supported(const Geom &g, int max_arm) {
-    static const int env = std::getenv("ADC_COST_FUSE") ? std::atoi(std::getenv("ADC_COST_FUSE")) : 1;
+    const int env = g.tune.cost_fuse;
     const int vec = (g.Dp >= 128 && g.Dp % 2 == 0) ? 2 : 1;
     // room for at least a 128-position segment of right-row entries next to the ring and the tables
     const long long room = (80 * 1024 - (long long)(2 * max_arm + 2 * PAIR_B) * 64 * vec * 4 - 836 * 4) / 8 - 2 * max_arm - (64 * vec - 1);
@@ -1068,7 +1141,7 @@ void launch_aggregate_first_pass_with_cost(const Planes &p, const float *lut_ad,
 void launch_aggregate_pass(const float *src, float *dst, const uint32_t *arms, const uint32_t *cnt,
                            const Geom &g, int vertical, int max_arm, int variant, hipStream_t s) {
     // deepest fill look-ahead (6, 4 or 2 iterations) whose ring still fits 64 KB of LDS
-    static const int depth_env = std::getenv("ADC_AGG_DEPTH") ? std::atoi(std::getenv("ADC_AGG_DEPTH")) : 6;
+    const int depth_env = g.tune.agg_depth;
     const bool strides_ok = (long long)g.W * g.Dp * (AGG_WAVES + 1) < (1ll << 31);
     const int vec = (g.Dp >= 128 && g.Dp % 2 == 0) ? 2 : 1;
     int depth = 0, R = 0;

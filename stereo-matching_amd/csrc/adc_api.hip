@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -34,7 +35,8 @@ struct adc_handle {
     bool debug_taps = false;
     bool profiling = false;
     bool have_times = false;
-    int agg_variant = 0;
+    int agg_launches = 8;  // aggregation launches of the last match: 5 with fused same-axis pairs, else 8
+    Tuning tune{};                     // development switches, read in adc_create (see Tuning)
     adc_option opt{};
     Geom g{};
     hipStream_t stream = nullptr;
@@ -182,7 +184,8 @@ int do_initialize(adc_handle *h, int32_t W, int32_t H, const adc_option *opt, hi
     if (W <= 0 || H <= 0) return h->fail(ADC_ERR_ARG, "adc_initialize: width and height must be positive");
     const long long D64 = (long long)opt->max_disparity - (long long)opt->min_disparity;
     if (D64 <= 0) return h->fail(ADC_ERR_ARG, "adc_initialize: max_disparity must exceed min_disparity");
-    if (D64 > 1024) return h->fail(ADC_ERR_UNSUPPORTED, "adc_initialize: more than 1024 disparities not supported");
+    // (the widest layout the scanline kernels are built and tested for: 8 disparities per lane)
+    if (D64 > 512) return h->fail(ADC_ERR_UNSUPPORTED, "adc_initialize: more than 512 disparities not supported");
     if (opt->lambda_ad <= 0 || opt->lambda_census <= 0)
         return h->fail(ADC_ERR_ARG, "adc_initialize: lambda_ad and lambda_census must be positive");
     if ((unsigned long long)W * (unsigned long long)H >= (1ull << 31))
@@ -201,6 +204,7 @@ int do_initialize(adc_handle *h, int32_t W, int32_t H, const adc_option *opt, hi
     HIPCHK(h, scanline_setup_device());
     h->opt = *opt;
     Geom &g = h->g;
+    g.tune = h->tune;
     g.W = W; g.H = H; g.dmin = opt->min_disparity; g.dmax = opt->max_disparity; g.D = (int)D64;
     g.NV = 1;
     while (64 * g.NV < g.D) g.NV *= 2;
@@ -288,7 +292,7 @@ int do_initialize(adc_handle *h, int32_t W, int32_t H, const adc_option *opt, hi
     HIPCHK(h, hipMemcpyAsync(h->ray_dx, dx.data(), nray * sizeof(double), hipMemcpyHostToDevice, s0));
     // round((double)y + v) == y + round(v) for every integer |y| < 2^16 unless v is within a few ulps
     // (of 2^17) of a half-integer; with a margin of 1e-6 the integer offsets can replace the doubles.
-    bool int_ok = h->ray_len <= 32000 && !std::getenv("ADC_INTERP_DOUBLE");
+    bool int_ok = h->ray_len <= 32000 && !h->tune.interp_double;
     std::vector<uint32_t> off(nray);
     for (size_t i = 0; int_ok && i < nray; i++) {
         const double ry = std::round(dy[i]), rx = std::round(dx[i]);
@@ -319,6 +323,24 @@ int do_initialize(adc_handle *h, int32_t W, int32_t H, const adc_option *opt, hi
     h->initialized = true;
     h->err.clear();
     return ADC_OK;
+}
+
+// The development switches of a new handle: the defaults, unless ADC_DEBUG_ENV is set to a non-zero value -- then
+// every ADC_* variable named in Tuning overrides its field. Nothing else in the library reads the environment.
+Tuning tuning_from_env() {
+    Tuning t;
+    const char *dbg = std::getenv("ADC_DEBUG_ENV");
+    if (!dbg || std::atoi(dbg) == 0) return t;
+    auto get = [](const char *name, int &field) {
+        const char *v = std::getenv(name);
+        if (v) field = std::atoi(v);
+    };
+    get("ADC_AGG_VARIANT", t.agg_variant); get("ADC_AGG_FUSE", t.agg_fuse); get("ADC_AGG_PAIR", t.agg_pair);
+    get("ADC_COST_FUSE", t.cost_fuse); get("ADC_AGG_DEPTH", t.agg_depth); get("ADC_AGG_MODE", t.agg_mode);
+    get("ADC_WTA_FUSED", t.wta_fused); get("ADC_WTA_SCALAR", t.wta_scalar); get("ADC_INTERP_DOUBLE", t.interp_double);
+    get("ADC_SCAN_SPLIT", t.scan_split); get("ADC_SCAN_HYBRID", t.scan_hybrid); get("ADC_HYB_MAIN", t.hyb_main);
+    get("ADC_HYB_LEAN", t.hyb_lean); get("ADC_SCAN_LEAN", t.scan_lean);
+    return t;
 }
 
 inline int max_arm_of(const adc_option &o) {
@@ -353,13 +375,13 @@ int enqueue_match(adc_handle *h, const uint8_t *d_l, const uint8_t *d_r, float *
     launch_sup_counts(pl.arms, pl.cnt_h, pl.cnt_v, pl.cnt_h32, pl.cnt_v32, g.W, g.H, s);
     launch_scan_records(pl, g, s);
     const int cap = max_arm_of(o);
-    const bool fuse_pairs = h->agg_variant == 0 && aggregate_pair_fusion_supported(g, cap);
+    const bool fuse_pairs = h->tune.agg_variant == 0 && aggregate_pair_fusion_supported(g, cap);
     // horizontal dividing passes divide by the vertical-first counts, vertical ones by the horizontal-first counts
     if (fuse_pairs) launch_pair_descriptors(pl.arms, pl.cnt_v32, pl.cnt_h32, pl.pair_h, pl.pair_v, g, cap, s);
 
     // The initial cost volume is computed inside the first aggregation pass when that is possible; it is
     // materialised (ComputeCostCuda as a kernel of its own) when its tap is wanted or the pass cannot hold it.
-    const bool fuse_cost = !h->debug_taps && h->agg_variant == 0 && aggregate_cost_fusion_supported(g, cap);
+    const bool fuse_cost = !h->debug_taps && h->tune.agg_variant == 0 && aggregate_cost_fusion_supported(g, cap);
     MARK(ADC_STAGE_COST);
     KMARK(ADC_KERNEL_COST);
     if (!fuse_cost) launch_cost_init(pl, g, h->lut_ad, h->lut_cen, h->vol_b, s);
@@ -369,6 +391,7 @@ int enqueue_match(adc_handle *h, const uint8_t *d_l, const uint8_t *d_r, float *
     // passes H, V/cntH | V, H/cntV | H, V/cntH | V, H/cntV. `cur` is the volume holding the latest result.
     MARK(ADC_STAGE_AGGR);
     float *cur_v, *oth_v;
+    h->agg_launches = fuse_pairs ? 5 : N_AGG_PASSES;
     if (fuse_pairs) {
         // five launches: pass 0 | passes 1+2 | 3+4 | 5+6 | pass 7 -- a dividing pass and the same-axis pass behind
         // it share a launch and the volume between them never leaves the CU
@@ -397,10 +420,10 @@ int enqueue_match(adc_handle *h, const uint8_t *d_l, const uint8_t *d_r, float *
             if (it == 0 && fuse_cost)
                 launch_aggregate_first_pass_with_cost(pl, h->lut_ad, h->lut_cen, h->vol_a, g, cap, s);
             else
-                launch_aggregate_pass(h->vol_b, h->vol_a, pl.arms, nullptr, g, hfirst ? 0 : 1, cap, h->agg_variant, s);
+                launch_aggregate_pass(h->vol_b, h->vol_a, pl.arms, nullptr, g, hfirst ? 0 : 1, cap, h->tune.agg_variant, s);
             KMARK(ADC_KERNEL_AGGR0 + 2 * it + 1);
             launch_aggregate_pass(h->vol_a, h->vol_b, pl.arms, hfirst ? pl.cnt_h32 : pl.cnt_v32, g, hfirst ? 1 : 0, cap,
-                                  h->agg_variant, s);
+                                  h->tune.agg_variant, s);
         }
         cur_v = h->vol_b; oth_v = h->vol_a;
     }
@@ -410,7 +433,6 @@ int enqueue_match(adc_handle *h, const uint8_t *d_l, const uint8_t *d_r, float *
     // ScanlineOptimizer::Optimize pass order and ping-pong (ADC/scanline_optimizer.cu:380-447): the result ends
     // in the volume the aggregation left its result in, the other one holds the third pass's output
     MARK(ADC_STAGE_SCAN);
-    if (h->debug_taps) KMARK(ADC_KERNEL_SCAN0);   // after the tap copy
     launch_scanline_pass(cur_v, oth_v, pl, g, h->sp, 0, 1, nullptr, s);
     KMARK(ADC_KERNEL_SCAN0 + 1);
     launch_scanline_pass(oth_v, cur_v, pl, g, h->sp, 0, 0, nullptr, s);
@@ -421,16 +443,15 @@ int enqueue_match(adc_handle *h, const uint8_t *d_l, const uint8_t *d_r, float *
     // frames where the pass is bound by HBM traffic and the extra instructions hide (1080p: +0.03 ms against a
     // 0.4 ms volume read). On small frames the pass is a bare serial chain per column and those instructions
     // more than double it (450x375x64: 154 against 66 us), while reading the small volume once more is cheap.
-    const char *wta_str = std::getenv("ADC_WTA_FUSED");   // (test hook: 0 / 1 force the separate / fused form)
-    const int wta_env = wta_str ? std::atoi(wta_str) : -1;
+    const int wta_env = h->tune.wta_fused;   // (test hook: 0 / 1 force the separate / fused form)
     const bool wta_fused = wta_env >= 0 ? wta_env != 0 : (long long)g.W * g.Dp >= 150000;
     launch_scanline_pass(oth_v, cur_v, pl, g, h->sp, 1, 0, wta_fused ? h->disp_a : nullptr, s);
     h->vol_final = cur_v;
     h->vol_aux = oth_v;
 
     MARK(ADC_STAGE_WTA);
+    KMARK(ADC_KERNEL_WTA_RIGHT);   // (in front of a separate left WTA: the last scanline pass's interval ends here)
     if (!wta_fused) launch_wta_left(cur_v, h->disp_a, g, s);
-    KMARK(ADC_KERNEL_WTA_RIGHT);
     launch_wta_right(cur_v, h->disp_r, g, s);
     KMARK(ADC_KERNEL_COUNT_);
     SNAP(h->snap_wta_l, h->disp_a, npx * sizeof(float));
@@ -527,8 +548,7 @@ adc_handle *adc_create(int device) {
     adc_handle *h = new (std::nothrow) adc_handle();
     if (!h) { g_thread_error = "adc_create: out of host memory"; return nullptr; }
     h->device = device;
-    const char *v = std::getenv("ADC_AGG_VARIANT");
-    if (v) h->agg_variant = std::atoi(v);
+    h->tune = tuning_from_env();
     return h;
 }
 
@@ -664,7 +684,7 @@ int adc_aggr_kernel_stats(adc_handle *h, int *launches, float *total_ms) {
     if (rc != ADC_OK) return rc;
     float sum = 0.0f;
     for (int i = 0; i < N_AGG_PASSES; i++) sum += t[ADC_KERNEL_AGGR0 + i];
-    if (launches) *launches = N_AGG_PASSES;
+    if (launches) *launches = h->agg_launches;
     if (total_ms) *total_ms = sum;
     return ADC_OK;
 }
@@ -933,6 +953,18 @@ int adc_match_device_static(int device, int32_t width, int32_t height, const adc
         c.ptr = static_cast<unsigned char *>(p);
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    {
+        // Not under stream capture: a re-layout sets kernel attributes, uploads tables from host memory and waits for
+        // the stream, which would invalidate the capture, and a replayed graph of a steady-state call (memset and copy
+        // nodes on the static array, the voting stamps of the captured frame) is not something this entry point
+        // supports. Refused before anything is enqueued, so the caller's capture stays intact.
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        e = hipStreamIsCapturing(s, &cap);
+        if (e != hipSuccess) return fail(c.h.fail_hip("hipStreamIsCapturing", e));
+        if (cap != hipStreamCaptureStatusNone)
+            return fail(c.h.fail(ADC_ERR_UNSUPPORTED, "adc_match_device_static: the stream is being captured into a graph; "
+                                                      "this entry point only runs on a stream that executes its work"));
+    }
     if (!c.valid || c.W != width || c.H != height || std::memcmp(&c.opt, opt, sizeof(adc_option)) != 0) {
         // lay the buffers out anew in the scratch (it keeps the previous call's contents: do_initialize clears
         // what must start at zero and uploads the tables for this option)

@@ -11,6 +11,26 @@
 
 namespace adc {
 
+// Development switches (kernel variants the tests and the A/B tools force). A handle takes them from the
+// environment ONCE, in adc_create, and only when ADC_DEBUG_ENV is set to a non-zero value; otherwise these defaults
+// hold and the launch path reads no environment variable.
+struct Tuning {
+    int agg_variant = 0;    // ADC_AGG_VARIANT   1: direct-global aggregation kernel
+    int agg_fuse = 1;       // ADC_AGG_FUSE      0: eight single aggregation passes
+    int agg_pair = 1;       // ADC_AGG_PAIR      0: one position per wave (ring kernel)
+    int cost_fuse = 1;      // ADC_COST_FUSE     0: the initial costs as a kernel of their own
+    int agg_depth = 6;      // ADC_AGG_DEPTH     fill look-ahead of the ring kernel
+    int agg_mode = 1;       // ADC_AGG_MODE      how the fused aggregation launch fills its first ring (see k_agg_fused)
+    int wta_fused = -1;     // ADC_WTA_FUSED     0 / 1: left WTA as its own kernel / inside the last scanline pass
+    int wta_scalar = 0;     // ADC_WTA_SCALAR    1: right WTA without 16-byte loads
+    int interp_double = 0;  // ADC_INTERP_DOUBLE 1: interpolation rays from the double tables
+    int scan_split = 1;     // ADC_SCAN_SPLIT    0 / 1 / 2: waves per scanline (never two / automatic / two where possible)
+    int scan_hybrid = 1;    // ADC_SCAN_HYBRID   0: no mixed launch
+    int hyb_main = -1;      // ADC_HYB_MAIN      rows of the mixed launch that get a wave of their own
+    int hyb_lean = 1;       // ADC_HYB_LEAN
+    int scan_lean = 1;      // ADC_SCAN_LEAN
+};
+
 // Frame geometry handed to every launcher. Volumes are f32[H][W][Dp] with Dp >= D the internal
 // disparity stride (D rounded up so each lane's disparity group is whole); entries k >= D are padding.
 struct Geom {
@@ -20,6 +40,7 @@ struct Geom {
     int Dp;  // internal stride of the disparity axis
     int NV;  // disparities per lane in the wave-per-pixel kernels: 64*NV >= D
     int simds;  // SIMDs of the handle's device (4 per compute unit): how many one-wave scanlines run side by side
+    Tuning tune;
 };
 
 // Per-pixel 2-D planes living in HBM for one handle.

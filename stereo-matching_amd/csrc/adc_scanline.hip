@@ -935,19 +935,13 @@ hipError_t scanline_setup_device() {
     if (e == hipSuccess) e = setup_nv<2>();
     if (e == hipSuccess) e = setup_nv<4>();
     if (e == hipSuccess) e = setup_nv<8>();
-    if (e == hipSuccess) e = setup_nv<16>();
     return e;
-}
-
-static int env_int(const char *name, int dflt) {
-    const char *v = std::getenv(name);
-    return v ? std::atoi(v) : dflt;
 }
 
 void launch_scanline_pass(const float *src, float *dst, const Planes &p, const Geom &g,
                           const ScanParams &sp, int vertical, int forward, float *disp_wta, hipStream_t s) {
-    // How a pass is spread over the chip (ADC_SCAN_SPLIT: 0 one wave per scanline always; 1 automatic; 2 two
-    // waves per scanline wherever the kernel allows; ADC_SCAN_HYBRID=0 takes the mixed launch out of 1).
+    // How a pass is spread over the chip (Tuning::scan_split: 0 one wave per scanline always; 1 automatic; 2 two
+    // waves per scanline wherever the kernel allows; Tuning::scan_hybrid = 0 takes the mixed launch out of 1).
     // Automatic, horizontal passes only -- a vertical pass has a scanline per column, plenty for the SIMDs:
     //   rows <= SIMDs                 one wave per row (the pass then runs at the HBM ceiling);
     //   SIMDs < rows <= 1.5 x SIMDs   mixed launch: one wave per row for `rows_main` rows, four light waves
@@ -955,20 +949,20 @@ void launch_scanline_pass(const float *src, float *dst, const Planes &p, const G
     //                                 the four passes); rows_main = max(3/4 SIMDs, 2 rows - 3/2 SIMDs), the
     //                                 best of the values measured at 1080, 1200 and 1440 rows;
     //   more rows, or D = 512         two waves per row.
-    const int split_env = env_int("ADC_SCAN_SPLIT", 1);
+    const int split_env = g.tune.scan_split;
     const bool split_ok = !disp_wta && g.Dp == g.D && (g.NV == 4 || g.NV == 8) && g.D == 64 * g.NV;
     bool split = split_ok && split_env >= 2;
     if (split_ok && split_env == 1 && !vertical) {
         const int simds = g.simds;   // of the handle's own device
         split = g.H > simds;
-        if (split && g.NV == 4 && simds >= 16 && g.H <= simds + simds / 2 && env_int("ADC_SCAN_HYBRID", 1)) {
+        if (split && g.NV == 4 && simds >= 16 && g.H <= simds + simds / 2 && g.tune.scan_hybrid) {
             typedef ScanCfg<4, false, HYB_RS> C;
             int rows_main = std::max(simds / 4 * 3, 2 * g.H - simds / 2 * 3);
-            rows_main = env_int("ADC_HYB_MAIN", rows_main);
+            if (g.tune.hyb_main >= 0) rows_main = g.tune.hyb_main;
             rows_main = std::min(std::min(rows_main, simds), g.H - 1) & ~3;
             typedef ScanCfgSplit<4, 1, false> CL;
             const int wgs = rows_main / 4 + (g.H - rows_main);
-            const int lean_main = wgs <= simds / 2 && env_int("ADC_HYB_LEAN", 1);   // two workgroups per CU
+            const int lean_main = wgs <= simds / 2 && g.tune.hyb_lean;   // two workgroups per CU
             const size_t lds_main = lean_main ? (size_t)4 * CL::RS * CL::SLOT_B : (size_t)4 * C::RS * C::SLOT_B;
             const size_t lds_rest = scan_split_lds<1, 4>();
             k_scanline_hybrid<<<dim3(rows_main / 4 + (g.H - rows_main)), dim3(256), std::max(lds_main, lds_rest), s>>>(
@@ -981,7 +975,7 @@ void launch_scanline_pass(const float *src, float *dst, const Planes &p, const G
         else launch_split<4>(src, dst, p, g, sp, vertical, forward, s);
         return;
     }
-    if (g.Dp == g.D && g.D == 64 * g.NV && g.NV <= 8 && env_int("ADC_SCAN_LEAN", 1)) {
+    if (g.Dp == g.D && g.D == 64 * g.NV && g.NV <= 8 && g.tune.scan_lean) {
         const int nlines = vertical ? g.W : g.H;
         const RecSrc rec = rec_source(p, g, vertical, forward);
         dim3 grid((nlines + 3) / 4), block(256);
@@ -1013,8 +1007,7 @@ void launch_scanline_pass(const float *src, float *dst, const Planes &p, const G
         case 1: ADC_NV(1); break;
         case 2: ADC_NV(2); break;
         case 4: ADC_NV(4); break;
-        case 8: ADC_NV(8); break;
-        default: ADC_NV(16); break;
+        default: ADC_NV(8); break;   // (adc_initialize admits at most 512 disparities: NV <= 8)
     }
 #undef ADC_NV
 }

@@ -173,7 +173,7 @@ void launch_wta_left(const float *cost, float *disp_l, const Geom &g, hipStream_
 
 void launch_wta_right(const float *cost, float *disp_r, const Geom &g, hipStream_t s) {
     dim3 grid((g.W + WR_PX - 1) / WR_PX, g.H);
-    if (g.Dp % 4 == 0 && g.D % 4 == 0 && !std::getenv("ADC_WTA_SCALAR"))
+    if (g.Dp % 4 == 0 && g.D % 4 == 0 && !g.tune.wta_scalar)
         k_wta_right<true><<<grid, dim3(256), 0, s>>>(cost, disp_r, g.W, g.H, g.dmin, g.D, g.Dp);
     else
         k_wta_right<false><<<grid, dim3(256), 0, s>>>(cost, disp_r, g.W, g.H, g.dmin, g.D, g.Dp);

@@ -52,7 +52,9 @@ def test_argument_errors_without_device(pkg):
     assert not h.Initialize(10, -1, o) and h.status == pkg.adcensus.ADC_ERR_ARG
     assert not h.Initialize(10, 10, pkg.ADCensusOption(min_disparity=5, max_disparity=5)) and h.status == pkg.adcensus.ADC_ERR_ARG
     assert not h.Initialize(10, 10, pkg.ADCensusOption(max_disparity=2000)) and h.status == pkg.adcensus.ADC_ERR_UNSUPPORTED
-    assert "1024" in h.last_error()
+    assert "512" in h.last_error()
+    # 512 disparities is the widest layout the kernels are built for; one more is refused, not attempted
+    assert not h.Initialize(10, 10, pkg.ADCensusOption(min_disparity=-3, max_disparity=510)) and h.status == pkg.adcensus.ADC_ERR_UNSUPPORTED
     assert pkg.lib().adc_buffer_bytes(h._h, 0) == 0
     h.close()
 

@@ -224,12 +224,14 @@ def test_more_rows_than_simds(pkg, orc, synth, W, H):
 @pytest.mark.parametrize("mode", ["0", "2"])
 def test_scanline_wave_layouts(pkg, orc, synth, monkeypatch, mode):
     """ADC_SCAN_SPLIT=0: one wave per scanline in every pass; 2: two waves per scanline in every pass that allows it."""
+    monkeypatch.setenv("ADC_DEBUG_ENV", "1")   # a handle reads the ADC_* switches in adc_create, only with this set
     monkeypatch.setenv("ADC_SCAN_SPLIT", mode)
     L, R, _ = synth.pair(82, 200, 120, 256)
     _scan_volume_and_map_match(pkg, orc, L, R, 256)
 
 
 def test_direct_aggregation_kernel(pkg, orc, synth, monkeypatch):
+    monkeypatch.setenv("ADC_DEBUG_ENV", "1")
     monkeypatch.setenv("ADC_AGG_VARIANT", "1")
     L, R, _ = synth.pair(23, 170, 90, 70)
     check_against_oracle(pkg, orc, L, R, max_disparity=70)
@@ -460,9 +462,14 @@ def test_match_from_pinned_memory_and_timers(pkg, orc, synth):
     x = h.transfer_times()
     assert x["host_in"] > 0 and x["host_out"] > 0
     k, st = h.kernel_times(), h.stage_times()
-    assert all(k["aggr%d" % i] > 0 for i in range(8)) and all(k["scan%d" % i] > 0 for i in range(4)) and k["wta_right"] > 0
+    # (a launch that runs two passes reports under the first of them: the second is a back-to-back event pair, 0 or more)
+    launches, total = h.aggr_kernel_stats()
+    assert launches in (5, 8)
+    own = (0, 1, 3, 5, 7) if launches == 5 else range(8)
+    assert all(k["aggr%d" % i] > 0 for i in own) and all(k["aggr%d" % i] >= 0 for i in range(8))
+    assert all(k["scan%d" % i] > 0 for i in range(4)) and k["wta_right"] > 0
     assert sum(k["aggr%d" % i] for i in range(8)) <= st["aggr"] * 1.02 + 0.01
-    assert abs(h.aggr_kernel_stats()[1] - sum(k["aggr%d" % i] for i in range(8))) < 1e-3
+    assert abs(total - sum(k["aggr%d" % i] for i in range(8))) < 1e-3
     h.close()
 
 
@@ -504,6 +511,7 @@ def test_frame_batch_at_size_on_one_gpu(pkg, synth):
 def test_left_wta_fused_and_separate(pkg, orc, synth, monkeypatch, fused, D, dmin):
     """The left-view WTA as part of the last scanline pass (large frames) and as a kernel of its own (small
     frames) are the same bits; ADC_WTA_FUSED forces either on a small frame."""
+    monkeypatch.setenv("ADC_DEBUG_ENV", "1")
     monkeypatch.setenv("ADC_WTA_FUSED", fused)
     L, R, _ = synth.pair(170, 180, 70, max(D, 8))
     got = gpu_match(pkg, L, R, min_disparity=dmin, max_disparity=dmin + D)
@@ -525,6 +533,7 @@ def test_fused_aggregation_pairs(pkg, orc, synth, monkeypatch, W, H, dmin, dmax,
     """The dividing aggregation pass and the same-axis pass behind it run as one launch wherever the kernel's rings
     fit the LDS (the default); ADC_AGG_FUSE=0 runs all eight passes on their own. Either way every tap must be the
     oracle's bits, with and without the taps' separate cost kernel."""
+    monkeypatch.setenv("ADC_DEBUG_ENV", "1")
     monkeypatch.setenv("ADC_AGG_FUSE", fuse)
     L, R, _ = synth.pair(180, max(W, 16), max(H, 16), max(dmax - dmin, 8))
     L, R = np.ascontiguousarray(L[:H, :W]), np.ascontiguousarray(R[:H, :W])

@@ -86,3 +86,62 @@ def test_static_scratch_limits(pkg):
     pkg.ADCensusStereo.match_device_static(0, 64, 64, pkg.ADCensusOption(max_disparity=16), small.data_ptr(), small.data_ptr(),
                                            o2.data_ptr(), None)
     torch.cuda.synchronize()
+
+
+def test_static_scratch_allocates_no_device_memory(pkg, synth):
+    """What the entry point exists for: the GPU's free memory is the same before and after its calls, re-layouts for
+    another size and another option included (hipMemGetInfo through torch; inputs and outputs are allocated first)."""
+    import torch
+    dev = torch.device("cuda:0")
+    cases = []
+    for seed, W, H, opt in [(93, 256, 160, dict(max_disparity=48)), (94, 130, 100, dict(max_disparity=32)),
+                            (93, 256, 160, dict(max_disparity=48, lambda_ad=8))]:
+        L, R = synth.pair(seed, W, H, 48)[:2]
+        cases.append((W, H, pkg.ADCensusOption(**opt), torch.from_numpy(L).to(dev), torch.from_numpy(R).to(dev),
+                      torch.empty((H, W), dtype=torch.float32, device=dev)))
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run_all():
+        for W, H, o, tl, tr, td in cases + cases[:1]:          # three layouts, then the first one again
+            pkg.ADCensusStereo.match_device_static(0, W, H, o, tl.data_ptr(), tr.data_ptr(), td.data_ptr(), stream)
+            pkg.ADCensusStereo.match_device_static(0, W, H, o, tl.data_ptr(), tr.data_ptr(), td.data_ptr(), stream)   # no re-layout
+        torch.cuda.synchronize()
+
+    run_all()                                                   # code objects loaded, the runtime's own pools warm
+    free0 = torch.cuda.mem_get_info()[0]
+    run_all()
+    assert torch.cuda.mem_get_info()[0] == free0
+
+
+def test_static_scratch_refuses_a_capturing_stream(pkg, synth):
+    """On a stream that is being captured into a graph the entry point enqueues nothing and says so (a re-layout would
+    invalidate the capture; replaying a captured frame is not supported); the caller's capture stays usable and the
+    entry point works as before afterwards."""
+    import torch
+    dev = torch.device("cuda:0")
+    W, H, D = 200, 120, 40
+    L, R = synth.pair(95, W, H, D)[:2]
+    want = _reference(pkg, torch, L, R, max_disparity=D)
+    opt = pkg.ADCensusOption(max_disparity=D)
+    tl, tr = torch.from_numpy(L).to(dev), torch.from_numpy(R).to(dev)
+    td = torch.zeros((H, W), dtype=torch.float32, device=dev)
+    probe = torch.zeros(16, device=dev)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        pkg.ADCensusStereo.match_device_static(0, W, H, opt, tl.data_ptr(), tr.data_ptr(), td.data_ptr(), s.cuda_stream)
+    s.synchronize()
+    assert np.array_equal(td.cpu().numpy(), want)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        probe.add_(1.0)                                           # the caller's own captured work
+        for w in (W, W - 8):                                      # the same size (no re-layout needed) and another one
+            with pytest.raises(RuntimeError, match="captured"):
+                pkg.ADCensusStereo.match_device_static(0, w, H, opt, tl.data_ptr(), tr.data_ptr(), td.data_ptr(), s.cuda_stream)
+    graph.replay()                                                # the capture was left intact: only the caller's node runs
+    torch.cuda.synchronize()
+    assert float(probe.sum()) == 16.0
+    td.fill_(-3.0)
+    with torch.cuda.stream(s):
+        pkg.ADCensusStereo.match_device_static(0, W, H, opt, tl.data_ptr(), tr.data_ptr(), td.data_ptr(), s.cuda_stream)
+    s.synchronize()
+    assert np.array_equal(td.cpu().numpy(), want)

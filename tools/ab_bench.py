@@ -11,7 +11,7 @@ for name in sys.argv[1:]:
     env = dict(os.environ)
     if name != "base":
         env["ADC_LIB_PATH"] = os.path.join(root, "stereo-matching_amd", "lib", "variants", "libadc_%s.so" % name)
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--steps", os.environ.get("AB_STEPS", "10")],
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--quick", "--steps", os.environ.get("AB_STEPS", "10")],
                        env=env, capture_output=True, text=True, timeout=300)
     if p.returncode != 0:
         print(name, "FAILED", p.stderr[-500:])

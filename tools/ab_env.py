@@ -9,10 +9,11 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cases = sys.argv[1:]
 for case in cases + cases:
     env = dict(os.environ)
+    env["ADC_DEBUG_ENV"] = "1"   # the library reads its ADC_* switches only with this set
     for kv in case.split(","):
         k, v = kv.split("=")
         env[k] = v
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--steps", os.environ.get("AB_STEPS", "10")],
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--quick", "--steps", os.environ.get("AB_STEPS", "10")],
                        env=env, capture_output=True, text=True, timeout=300)
     if p.returncode:
         print(case, "FAILED", p.stderr[-800:])

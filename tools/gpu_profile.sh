@@ -14,9 +14,9 @@ fi
 timeout -k 10 300 python bench.py > "$out/bench.json" 2> "$out/bench.err" || { tail "$out/bench.err"; exit 1; }
 cat "$out/bench.json"
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python3 "$root/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$out/kt.log" 2>&1 || { tail "$out/kt.log"; exit 1; }
-timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$out/pmc_fetch.log" 2>&1 || { tail "$out/pmc_fetch.log"; exit 1; }
-timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$out/pmc_write.log" 2>&1 || { tail "$out/pmc_write.log"; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python3 "$root/bench.py" --steps 10 --warmup 2 --quick > "$out/kt.log" 2>&1 || { tail "$out/kt.log"; exit 1; }
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 "$root/bench.py" --steps 2 --warmup 1 --quick > "$out/pmc_fetch.log" 2>&1 || { tail "$out/pmc_fetch.log"; exit 1; }
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python3 "$root/bench.py" --steps 2 --warmup 1 --quick > "$out/pmc_write.log" 2>&1 || { tail "$out/pmc_write.log"; exit 1; }
 cd "$root"
 python tools/pmc_summary.py "$out/pmc_fetch" > "$out/pmc_fetch_summary.txt"
 python tools/pmc_summary.py "$out/pmc_write" > "$out/pmc_write_summary.txt"

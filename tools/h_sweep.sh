@@ -6,7 +6,7 @@ tag=$1; shift
 root=$(pwd); export TMPDIR=/tmp; cd /tmp
 for hh in "$@"; do
   out=$root/gpurun_out/hs_${tag}_$hh; mkdir -p $out
-  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 $root/bench.py --steps 6 --warmup 2 --no-cpu-baseline --height $hh > $out/log.txt 2>&1 || exit 1
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 $root/bench.py --steps 6 --warmup 2 --quick --height $hh > $out/log.txt 2>&1 || exit 1
   find $out/kt -name '*kernel_stats.csv' -exec cp {} $out/kernel_stats.csv \;
   rm -rf $out/kt
   python3 - $out/kernel_stats.csv $hh <<'PY'

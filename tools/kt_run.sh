@@ -7,7 +7,7 @@ out=$root/gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 cd /tmp
-timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python3 "$root/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$out/kt.log" 2>&1 || { tail "$out/kt.log"; exit 1; }
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python3 "$root/bench.py" --steps 10 --warmup 2 --quick > "$out/kt.log" 2>&1 || { tail "$out/kt.log"; exit 1; }
 cd "$root"
 find "$out/kt" -name '*kernel_stats.csv' -exec cp {} "$out/kernel_stats.csv" \;
 find "$out/kt" -name '*kernel_trace.csv' -exec cp {} "$out/kernel_trace.csv" \;

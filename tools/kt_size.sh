@@ -4,7 +4,7 @@ set -o pipefail
 tag=$1; W=$2; H=$3; D=$4
 root=$(pwd); out=$root/gpurun_out/$tag; mkdir -p "$out"
 export TMPDIR=/tmp; cd /tmp
-timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python3 "$root/bench.py" --steps 40 --warmup 5 --no-cpu-baseline --width $W --height $H --disp $D > "$out/kt.log" 2>&1 || { tail "$out/kt.log"; exit 1; }
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python3 "$root/bench.py" --steps 40 --warmup 5 --quick --width $W --height $H --disp $D > "$out/kt.log" 2>&1 || { tail "$out/kt.log"; exit 1; }
 cd "$root"
 find "$out/kt" -name '*kernel_stats.csv' -exec cp {} "$out/kernel_stats.csv" \;
 find "$out/kt" -name '*kernel_trace.csv' -exec cp {} "$out/kernel_trace.csv" \;

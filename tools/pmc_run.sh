@@ -7,7 +7,7 @@ out=$root/gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 cd /tmp
-timeout -s KILL 240 rocprofv3 --pmc "$@" --output-format csv -d "$out/raw" -- python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$out/log.txt" 2>&1 || { tail "$out/log.txt"; exit 1; }
+timeout -s KILL 240 rocprofv3 --pmc "$@" --output-format csv -d "$out/raw" -- python3 "$root/bench.py" --steps 2 --warmup 1 --quick > "$out/log.txt" 2>&1 || { tail "$out/log.txt"; exit 1; }
 cd "$root"
 python tools/pmc_summary.py "$out/raw" > "$out/summary.txt"
 rm -rf "$out/raw"

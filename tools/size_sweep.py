@@ -10,7 +10,7 @@ sizes = sys.argv[1:] or ["450x375x64", "640x480x128", "1280x720x128", "1280x720x
 for sz in sizes:
     W, H, D = (int(v) for v in sz.split("x"))
     steps = "50" if W * H * D < 2e8 else "6"
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--steps", steps, "--warmup", "2",
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--quick", "--steps", steps, "--warmup", "2",
                         "--width", str(W), "--height", str(H), "--disp", str(D)], capture_output=True, text=True, timeout=600)
     if p.returncode:
         print(sz, "FAILED", p.stderr[-800:])
