@@ -305,11 +305,13 @@ __device__ __forceinline__ typename VecT<VEC>::T div_by_count(typename VecT<VEC>
 // COST: the pass is the first one (horizontal, no division) and its input is not read from a volume but
 // computed on the spot: ComputeCostCuda's expression (ADC/cost_computor.cu:151-207)
 //     ((1 - e_ad[sum|dBGR|]) + 1) - e_cen[popcount(cenL ^ cenR)],   1.0f where x-d is outside the image,
-// evaluated per ring slot from the right row's {pixel, census} entries and the two exp tables staged in
-// LDS. The initial cost volume then never exists in HBM (one volume write and one volume read less).
+// evaluated per ring slot from the right row's {pixel, census} entries and two tables staged in LDS:
+// t_ad[s] = (1 - e_ad[s]) + 1 (the same two fp32 operations, done once per table entry on the host instead of
+// once per volume element here) and e_cen. The initial cost volume then never exists in HBM (one volume write
+// and one volume read less).
 struct CostSrc {
     const uint32_t *pix_l, *pix_r, *cen_l, *cen_r;
-    const float *lut_ad, *lut_cen;
+    const float *lut_ad1, *lut_cen;   // t_ad[766], e_cen[65]
     int dmin, D;
 };
 // FULLD: Dp is a multiple of the chunk (64*VEC disparities), so every lane of every chunk is live and the
@@ -361,11 +363,12 @@ k_agg_pair(const float *__restrict__ src, float *__restrict__ dst, const uint32_
             }
             s_r[i] = v;
         }
-        for (int i = threadIdx.x; i < 766; i += AGG_WAVES * 64) s_ad[i] = cs.lut_ad[i];
+        for (int i = threadIdx.x; i < 766; i += AGG_WAVES * 64) s_ad[i] = cs.lut_ad1[i];
         if (threadIdx.x < 65) s_cen[threadIdx.x] = cs.lut_cen[threadIdx.x];
         __syncthreads();
     }
     // costs of position p (a column of row `line`) for this chunk's disparities into ring slot q
+    const bool has_pad = COST && cs.D != Dp;               // (uniform: most sizes have no padding disparities at all)
     auto cost_fill = [&](int p, int q) {
         const size_t pi = (size_t)line * W + p;
         const uint32_t pl = cs.pix_l[pi], cl = cs.cen_l[pi];
@@ -374,13 +377,13 @@ k_agg_pair(const float *__restrict__ src, float *__restrict__ dst, const uint32_
             const int jj = h * 64 + lane;                  // disparity index inside the chunk = float inside the slot
             const int xr = p - cs.dmin - kc - jj;
             float c = 1.0f;
-            if (xr >= 0 && xr < W) {
+            if ((unsigned)xr < (unsigned)W) {
                 const uint2 r = s_r[xr - xr_base];
                 const uint32_t sad = __builtin_amdgcn_sad_u8(pl, r.x, 0u);
                 const uint32_t ham = __builtin_popcount(cl ^ r.y);
-                c = ((1.0f - s_ad[sad]) + 1.0f) - s_cen[ham];
+                c = s_ad[sad] - s_cen[ham];
             }
-            if (kc + jj >= cs.D) c = 0.0f;                 // padding past D holds zeros, as the volume does
+            if (has_pad && kc + jj >= cs.D) c = 0.0f;      // padding past D holds zeros, as the volume does
             ring[q * SLOT + jj] = c;
         }
     };
@@ -584,19 +587,78 @@ void launch_pair_descriptors(const uint32_t *arms, const uint32_t *cnt_for_h, co
                                                                               pair_desc_pad(max_arm));
 }
 
-// n consecutive slots from byte-free float pointer q, n known to be small most of the time (heads and tails)
+// ---- window sums of the fused kernel: ring positions as 32-bit LDS byte offsets ---------------------------------
+template <typename T>
+__device__ __forceinline__ T ring_read_o(uint32_t off) {
+    typedef const volatile T __attribute__((address_space(3))) *lds_ptr;
+    return *(lds_ptr)(uintptr_t)off;
+}
+// G consecutive slots from byte offset o added to one chain (CH == 1) or to both (CH == 2): all reads, then the adds
+template <int VEC, int CH, int G>
+__device__ __forceinline__ void group_add_o(typename VecT<VEC>::T &a0, typename VecT<VEC>::T &a1, uint32_t o) {
+    typedef typename VecT<VEC>::T vec_t;
+    constexpr uint32_t SB = 256 * VEC;          // bytes per slot
+    vec_t v[G];
+#pragma unroll
+    for (int u = 0; u < G; u++) v[u] = ring_read_o<vec_t>(o + u * SB);
+#pragma unroll
+    for (int u = 0; u < G; u++) {
+        a0 += v[u];
+        if (CH == 2) a1 += v[u];
+    }
+}
+// n consecutive slots (no wrap inside): batches of 16, then one group each of 8, 4, 2, 1 terms as the bits of n say
+template <int VEC, int CH>
+__device__ __forceinline__ void span_o(typename VecT<VEC>::T &a0, typename VecT<VEC>::T &a1, uint32_t o, int n) {
+    constexpr uint32_t SB = 256 * VEC;
+    for (int i = 16; i <= n; i += 16, o += 16 * SB) group_add_o<VEC, CH, 16>(a0, a1, o);
+    if (n & 8) { group_add_o<VEC, CH, 8>(a0, a1, o); o += 8 * SB; }
+    if (n & 4) { group_add_o<VEC, CH, 4>(a0, a1, o); o += 4 * SB; }
+    if (n & 2) { group_add_o<VEC, CH, 2>(a0, a1, o); o += 2 * SB; }
+    if (n & 1) group_add_o<VEC, CH, 1>(a0, a1, o);
+}
+// Head and tail terms belong to one of the two windows only. Instead of summing them into a copy of that window's
+// accumulator and selecting the results back (four conditional moves per part), every such term goes to BOTH
+// accumulators through a fused multiply-add with a wave-uniform factor: 1.0f for the window it belongs to, 0.0f for
+// the other. fma(v, 1, a) rounds v + a exactly as the addition does, fma(v, 0, a) is a + 0 = a (v is a finite cost,
+// a >= +0): the same bits as before. Heads and tails are one term long most of the time.
 template <int VEC>
-__device__ __forceinline__ void short_span(typename VecT<VEC>::T &acc, const float *q, int n) {
-    if (n == 1) group_add<VEC, 1, 1>(acc, acc, q);
-    else if (n > 1) span<VEC, 1>(acc, acc, q, 0, n);
+__device__ __forceinline__ void masked_term(typename VecT<VEC>::T &a0, typename VecT<VEC>::T &a1, typename VecT<VEC>::T v, float m0, float m1) {
+    if constexpr (VEC == 1) {
+        a0 = __builtin_fmaf(v, m0, a0);
+        a1 = __builtin_fmaf(v, m1, a1);
+    } else {
+        typedef typename VecT<VEC>::T vec_t;
+        const vec_t w0 = {m0, m0}, w1 = {m1, m1};
+        a0 = __builtin_elementwise_fma(v, w0, a0);
+        a1 = __builtin_elementwise_fma(v, w1, a1);
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void masked_span_o(typename VecT<VEC>::T &a0, typename VecT<VEC>::T &a1, uint32_t o, int n, float m0, float m1) {
+    typedef typename VecT<VEC>::T vec_t;
+    constexpr uint32_t SB = 256 * VEC;
+    if (n == 1) {
+        masked_term<VEC>(a0, a1, ring_read_o<vec_t>(o), m0, m1);
+        return;
+    }
+    for (; n >= 4; n -= 4, o += 4 * SB) {
+        vec_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = ring_read_o<vec_t>(o + u * SB);
+#pragma unroll
+        for (int u = 0; u < 4; u++) masked_term<VEC>(a0, a1, v[u], m0, m1);
+    }
+    for (; n > 0; n--, o += SB) masked_term<VEC>(a0, a1, ring_read_o<vec_t>(o), m0, m1);
 }
 
-// The sums of the two windows of a pair from ring `rl` (R slots); q = slot of the pair's first position.
+// The sums of the two windows of a pair from the ring at LDS byte offset `base` (this lane's floats; R slots);
+// q = slot of the pair's first position.
 template <int VEC>
-__device__ __forceinline__ void desc_windows(typename VecT<VEC>::T &acc0, typename VecT<VEC>::T &acc1, const float *rl, int R,
+__device__ __forceinline__ void desc_windows(typename VecT<VEC>::T &acc0, typename VecT<VEC>::T &acc1, uint32_t base, int R,
                                              int q, uint32_t d) {
     typedef typename VecT<VEC>::T vec_t;
-    constexpr int SLOT = 64 * VEC;
+    constexpr uint32_t SB = 256 * VEC;
 #ifdef AGG_DIAG_ONE_TERM   // diagnostic: every window is one term (what is left is the kernel's memory skeleton)
     d = (d & 0x80000000u) | (1u << 14);
 #endif
@@ -604,51 +666,63 @@ __device__ __forceinline__ void desc_windows(typename VecT<VEC>::T &acc0, typena
     d = 0x80000000u | 14u | (1u << 7) | (28u << 14) | (1u << 22) | (1u << 30);
 #endif
     const int hn = (d >> 7) & 127, mn = (d >> 14) & 255, tn = (d >> 22) & 127;
-    const bool h1 = (d >> 29) & 1, t1 = (d >> 30) & 1;
+    // factors of the head's and the tail's terms for window 0 / window 1
+    // (1.0f or 0.0f made from the descriptor's bits by integer arithmetic: they stay in scalar registers)
+    const uint32_t one = 0x3f800000u;
+    const uint32_t h1b = ((d >> 29) & 1u) * one, t1b = ((d >> 30) & 1u) * one;
+    const float h1 = __uint_as_float(h1b), h0 = __uint_as_float(one - h1b);
+    const float t1 = __uint_as_float(t1b), t0 = __uint_as_float(one - t1b);
     int u = q - (int)(d & 127);
     if (u < 0) u += R;
     const vec_t zero = {};
-    vec_t hd = {};
     if (u + hn + mn + tn <= R) {
         // the run does not cross the end of the ring (three times out of four)
-        const float *p = rl + u * SLOT;
+        uint32_t o = base + (uint32_t)u * SB;
         if (hn == 0) {
             // both windows start at the same place: up to the end of the shorter one they are one and the same chain
             // of additions (a third to a half of all pairs: both arms stop at the same edge)
-            span<VEC, 1>(hd, hd, p, 0, mn);
-            acc0 = hd;
-            acc1 = hd;
+            vec_t c = zero;
+            span_o<VEC, 1>(c, c, o, mn);
+            acc0 = c;
+            acc1 = c;
         } else {
-            short_span<VEC>(hd, p, hn);
-            acc0 = h1 ? zero : hd;
-            acc1 = h1 ? hd : zero;
-            p += hn * SLOT;
-            span<VEC, 2>(acc0, acc1, p, 0, mn);
+            acc0 = zero;
+            acc1 = zero;
+            masked_span_o<VEC>(acc0, acc1, o, hn, h0, h1);
+            o += (uint32_t)hn * SB;
+            span_o<VEC, 2>(acc0, acc1, o, mn);
         }
-        p += mn * SLOT;
-        vec_t tl = t1 ? acc1 : acc0;
-        short_span<VEC>(tl, p, tn);
-        acc0 = t1 ? acc0 : tl;
-        acc1 = t1 ? tl : acc1;
+        o += (uint32_t)mn * SB;
+        if (tn) masked_span_o<VEC>(acc0, acc1, o, tn, t0, t1);
     } else {
+        // the run crosses the end of the ring somewhere: every part is split at the wrap
+        auto part = [&](int vs, int n, int kind) {   // kind 0: head, 1: single chain, 2: both chains, 3: tail
+            if (n <= 0) return;
+            const int n1 = min(n, R - vs);
+            for (int half = 0; half < 2; half++) {
+                const int cnt = half ? n - n1 : n1;
+                if (cnt <= 0) continue;
+                const uint32_t o = base + (half ? 0u : (uint32_t)vs * SB);
+                if (kind == 0) masked_span_o<VEC>(acc0, acc1, o, cnt, h0, h1);
+                else if (kind == 1) span_o<VEC, 1>(acc0, acc0, o, cnt);
+                else if (kind == 2) span_o<VEC, 2>(acc0, acc1, o, cnt);
+                else masked_span_o<VEC>(acc0, acc1, o, cnt, t0, t1);
+            }
+        };
+        acc0 = zero;
+        acc1 = zero;
         int v = u + hn;
         if (v >= R) v -= R;
         if (hn == 0) {
-            range1<VEC>(hd, rl, v, mn, R);
-            acc0 = hd;
-            acc1 = hd;
+            part(v, mn, 1);
+            acc1 = acc0;
         } else {
-            range1<VEC>(hd, rl, u, hn, R);
-            acc0 = h1 ? zero : hd;
-            acc1 = h1 ? hd : zero;
-            range2<VEC>(acc0, acc1, rl, v, mn, R);
+            part(u, hn, 0);
+            part(v, mn, 2);
         }
         v += mn;
         if (v >= R) v -= R;
-        vec_t tl = t1 ? acc1 : acc0;
-        range1<VEC>(tl, rl, v, tn, R);
-        acc0 = t1 ? acc0 : tl;
-        acc1 = t1 ? tl : acc1;
+        part(v, tn, 3);
     }
 }
 
@@ -698,7 +772,9 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
     for (int h = 0; h < VEC; h++) fok[h] = FULLD || kc + h * 64 + lane < Dp;
     const float *fsrc = src + lbase + lane;
     const bool kok = FULLD || kc + lane * VEC < Dp;
-    const float *rl1 = ring + lane * VEC, *rl2 = ring2 + lane * VEC;
+    const float *rl2 = ring2 + lane * VEC;
+    // this lane's floats of slot 0 of either ring, as LDS byte offsets (a generic LDS address: its low 32 bits)
+    const uint32_t ro1 = (uint32_t)(uintptr_t)(ring + lane * VEC), ro2 = (uint32_t)(uintptr_t)rl2;
 
     // Iteration j = -nlead, ..., 0, 1, ...: stage 1 on positions pa .. pa+B-1, pa = cap + B*(j+1); stage 2 on
     // o0 .. o0+B-1, o0 = B*j; fills of the inputs stage 1 of iteration j+2 adds to its windows (two blocks ahead:
@@ -858,7 +934,7 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
         // (b) stage 1: A of positions p, p + 1 into ring 2
         if (d1c.x) {
             vec_t acc0, acc1;
-            desc_windows<VEC>(acc0, acc1, rl1, R1, q1, d1c.x);
+            desc_windows<VEC>(acc0, acc1, ro1, R1, q1, d1c.x);
             acc0 = div_by_count<VEC>(acc0, __uint_as_float(d1c.y));
             *(lds_vec_ptr)(uintptr_t)(rl2 + qw * SLOT) = acc0;
             if (d1c.x >> 31) {
@@ -871,7 +947,7 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
         int nstore = 0;
         vec_t out0 = {}, out1 = {};
         if (d2c) {
-            desc_windows<VEC>(out0, out1, rl2, R2, q2, d2c);
+            desc_windows<VEC>(out0, out1, ro2, R2, q2, d2c);
             nstore = (d2c >> 31) ? 2 : 1;
         }
         if constexpr (REGFILL) {
@@ -1130,9 +1206,9 @@ bool aggregate_cost_fusion_supported(const Geom &g, int max_arm) {
     const long long room = (80 * 1024 - (long long)(2 * max_arm + 2 * PAIR_B) * 64 * vec * 4 - 836 * 4) / 8 - 2 * max_arm - (64 * vec - 1);
     return env && pair_kernel_ok(g, max_arm) && room >= 128;
 }
-void launch_aggregate_first_pass_with_cost(const Planes &p, const float *lut_ad, const float *lut_cen, float *dst,
+void launch_aggregate_first_pass_with_cost(const Planes &p, const float *lut_ad1, const float *lut_cen, float *dst,
                                            const Geom &g, int max_arm, hipStream_t s) {
-    const CostSrc cs = {p.pix_l, p.pix_r, p.cen_l, p.cen_r, lut_ad, lut_cen, g.dmin, g.D};
+    const CostSrc cs = {p.pix_l, p.pix_r, p.cen_l, p.cen_r, lut_ad1, lut_cen, g.dmin, g.D};
     const int vec = (g.Dp >= 128 && g.Dp % 2 == 0) ? 2 : 1;
     if (vec == 2) launch_pair<2>(nullptr, dst, p.arms, nullptr, g, 0, max_arm, &cs, s);
     else launch_pair<1>(nullptr, dst, p.arms, nullptr, g, 0, max_arm, &cs, s);

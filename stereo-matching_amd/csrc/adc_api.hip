@@ -48,6 +48,10 @@ struct adc_handle {
     hipEvent_t xfer_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // upload start/end, download start/end of adc_match
     bool have_xfer = false;
     float host_ms[2] = {0, 0};         // adc_match: staging copies in / out on the host (0 for pinned callers)
+    enum { N_PIN_CACHE = 6 };
+    const void *pin_ptr[N_PIN_CACHE] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // is_pinned_host's memory
+    bool pin_yes[N_PIN_CACHE] = {false, false, false, false, false, false};
+    int pin_next = 0;
     // arena mode: every device buffer is carved from [arena, arena + arena_size) instead of hipMalloc; no stream,
     // event or pinned host buffer is created (the caller's stream is used, profiling and adc_match are unavailable)
     unsigned char *arena = nullptr;
@@ -63,7 +67,7 @@ struct adc_handle {
     float *vol_final = nullptr, *vol_aux = nullptr;   // which of the two holds the final scanline volume / the third pass's output
     float *snap_init = nullptr, *snap_aggr = nullptr;
     // tables
-    float *lut_ad = nullptr, *lut_cen = nullptr;
+    float *lut_ad = nullptr, *lut_cen = nullptr, *lut_ad1 = nullptr;   // e_ad, e_cen, (1 - e_ad) + 1
     double *ray_dy = nullptr, *ray_dx = nullptr;
     uint32_t *ray_off = nullptr;   // rounded (dy, dx) offsets, or null when some entry sits too close to a rounding tie
     int ray_len = 0;
@@ -229,7 +233,7 @@ int do_initialize(adc_handle *h, int32_t W, int32_t H, const adc_option *opt, hi
     const size_t n_pair_h = pair_desc_count(H, W, arm_cap), n_pair_v = pair_desc_count(W, H, arm_cap);
     A(h->pl.pair_h, n_pair_h); A(h->pl.pair_v, n_pair_v);
     A(h->vol_a, nvol); A(h->vol_b, nvol);
-    A(h->lut_ad, 768); A(h->lut_cen, 68);
+    A(h->lut_ad, 768); A(h->lut_cen, 68); A(h->lut_ad1, 768);
     A(h->disp_a, npx); A(h->disp_b, npx); A(h->disp_r, npx); A(h->disp_final, npx);
     A(h->occ, npx); A(h->mis, npx); A(h->edge, npx);
     A(h->list_mis, npx); A(h->list_occ, npx); A(h->counters, ADC_NUM_COUNTERS);
@@ -261,11 +265,16 @@ int do_initialize(adc_handle *h, int32_t W, int32_t H, const adc_option *opt, hi
 
     // exp tables of the initial cost (ADC/cost_computor.cu:186,200-203): entry = expf of the float
     // argument, taken as the correctly rounded (float)exp((double)arg).
-    std::vector<float> ad(768, 0.0f), cen(68, 0.0f);
+    std::vector<float> ad(768, 0.0f), cen(68, 0.0f), ad1(768, 0.0f);
     for (int s = 0; s < 766; s++) {
         const float a = (float)s / 3.0f;
         const float arg = -a / (float)opt->lambda_ad;
         ad[s] = (float)std::exp((double)arg);
+        // the first two operations of ((1 - e1) + 1) - e2 (ADC/cost_computor.cu:203), in fp32 as the kernels did them
+        // per element (this file is compiled without FMA contraction; volatile keeps each rounding step)
+        volatile float t = 1.0f - ad[s];
+        t = t + 1.0f;
+        ad1[s] = t;
     }
     for (int k = 0; k < 65; k++) {
         const float arg = -(float)k / (float)opt->lambda_census;
@@ -273,6 +282,7 @@ int do_initialize(adc_handle *h, int32_t W, int32_t H, const adc_option *opt, hi
     }
     HIPCHK(h, hipMemcpyAsync(h->lut_ad, ad.data(), 768 * sizeof(float), hipMemcpyHostToDevice, s0));
     HIPCHK(h, hipMemcpyAsync(h->lut_cen, cen.data(), 68 * sizeof(float), hipMemcpyHostToDevice, s0));
+    HIPCHK(h, hipMemcpyAsync(h->lut_ad1, ad1.data(), 768 * sizeof(float), hipMemcpyHostToDevice, s0));
     // ray tables (ADC/multistep_refiner.cu:561-583, :642): ang += PI/16 with PI = 3.1415926f, accumulated in
     // double; entries m*sin(ang), m*cos(ang).
     std::vector<double> dy(nray, 0.0), dx(nray, 0.0);
@@ -398,7 +408,7 @@ int enqueue_match(adc_handle *h, const uint8_t *d_l, const uint8_t *d_r, float *
         KMARK(ADC_KERNEL_AGGR0);
         if (fuse_cost) {
             cur_v = h->vol_b; oth_v = h->vol_a;    // nothing lives in either volume yet
-            launch_aggregate_first_pass_with_cost(pl, h->lut_ad, h->lut_cen, cur_v, g, cap, s);
+            launch_aggregate_first_pass_with_cost(pl, h->lut_ad1, h->lut_cen, cur_v, g, cap, s);
         } else {
             cur_v = h->vol_a; oth_v = h->vol_b;
             launch_aggregate_pass(h->vol_b, cur_v, pl.arms, nullptr, g, 0, cap, 0, s);
@@ -418,7 +428,7 @@ int enqueue_match(adc_handle *h, const uint8_t *d_l, const uint8_t *d_r, float *
             const bool hfirst = (it % 2) == 0;
             KMARK(ADC_KERNEL_AGGR0 + 2 * it);
             if (it == 0 && fuse_cost)
-                launch_aggregate_first_pass_with_cost(pl, h->lut_ad, h->lut_cen, h->vol_a, g, cap, s);
+                launch_aggregate_first_pass_with_cost(pl, h->lut_ad1, h->lut_cen, h->vol_a, g, cap, s);
             else
                 launch_aggregate_pass(h->vol_b, h->vol_a, pl.arms, nullptr, g, hfirst ? 0 : 1, cap, h->tune.agg_variant, s);
             KMARK(ADC_KERNEL_AGGR0 + 2 * it + 1);
@@ -580,14 +590,21 @@ int adc_match_device(adc_handle *h, const uint8_t *d_left, const uint8_t *d_righ
     return enqueue_match(h, d_left, d_right, d_disp, s);
 }
 
-// true when p is host memory the GPU can copy from / to directly (hipHostMalloc or hipHostRegister)
-static bool is_pinned_host(const void *p) {
+// true when p is host memory the GPU can copy from / to directly (hipHostMalloc or hipHostRegister). The runtime's
+// query takes a noticeable fraction of a millisecond, and callers pass the same few buffers frame after frame: the
+// handle remembers the answers for the last pointers it saw. (A remembered "pinned" for memory that has meanwhile
+// been freed and handed out again as pageable is harmless: hipMemcpyAsync stages such a copy itself.)
+static bool is_pinned_host(adc_handle *h, const void *p) {
+    for (int i = 0; i < adc_handle::N_PIN_CACHE; i++)
+        if (h->pin_ptr[i] == p) return h->pin_yes[i];
     hipPointerAttribute_t a;
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
-        (void)hipGetLastError();   // an ordinary malloc pointer: not an error of ours
-        return false;
-    }
-    return a.type == hipMemoryTypeHost;
+    bool yes = false;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) (void)hipGetLastError();   // an ordinary malloc pointer: not an error of ours
+    else yes = a.type == hipMemoryTypeHost;
+    h->pin_ptr[h->pin_next] = p;
+    h->pin_yes[h->pin_next] = yes;
+    h->pin_next = (h->pin_next + 1) % adc_handle::N_PIN_CACHE;
+    return yes;
 }
 
 int adc_match(adc_handle *h, const uint8_t *left, const uint8_t *right, float *disp) {
@@ -601,7 +618,7 @@ int adc_match(adc_handle *h, const uint8_t *left, const uint8_t *right, float *d
     typedef std::chrono::steady_clock clk;
     // Pageable caller memory goes through the handle's pinned staging buffers; pinned caller memory is the
     // DMA source / target itself (no host copy on either side).
-    const bool pin_in = is_pinned_host(left) && is_pinned_host(right), pin_out = is_pinned_host(disp);
+    const bool pin_in = is_pinned_host(h, left) && is_pinned_host(h, right), pin_out = is_pinned_host(h, disp);
     const uint8_t *src_l = left, *src_r = right;
     const auto t0 = clk::now();
     if (!pin_in) {

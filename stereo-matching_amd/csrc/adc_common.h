@@ -85,7 +85,8 @@ void launch_aggregate_pass(const float *src, float *dst, const uint32_t *arms, c
 // The first pass (horizontal, no division) with the initial cost volume computed inside the kernel
 // instead of being read: only when aggregate_cost_fusion_supported().
 bool aggregate_cost_fusion_supported(const Geom &g, int max_arm);
-void launch_aggregate_first_pass_with_cost(const Planes &p, const float *lut_ad, const float *lut_cen, float *dst,
+// lut_ad1[s] = (1.0f - e_ad[s]) + 1.0f, evaluated in fp32 on the host
+void launch_aggregate_first_pass_with_cost(const Planes &p, const float *lut_ad1, const float *lut_cen, float *dst,
                                            const Geom &g, int max_arm, hipStream_t s);
 
 // A dividing pass and the plain pass that follows it along the same axis (passes 1+2, 3+4, 5+6 of the eight)

@@ -10,11 +10,14 @@
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 #define REP16(x) x x x x x x x x x x x x x x x x
+#define REP8(x) x x x x x x x x
 
 // MODE 0: one dependent chain of v_pk_add_f32          1: two interleaved chains of v_pk_add_f32
 //      2: one dependent chain of v_add_f32             3: four independent chains of v_pk_add_f32
 //      4: ds_read_b64 only (16 in flight, then wait)   5: 16 x ds_read_b64, then 16 x (2 pk adds) with counted waits
 //      7: pattern 5 plus 16 SALU instructions in between
+//      8: pattern 5 plus 8 taken branches (compare + s_cbranch over one instruction)     9: the same, not taken
+//     10: pattern 5 plus 16 v_cndmask_b32     11: pattern 5 with s_waitcnt lgkmcnt(0) before the adds (as the compiler emits)
 template <int MODE>
 __global__ void __launch_bounds__(1024) k_probe(float *out, int iters) {
     extern __shared__ float lds[];
@@ -44,11 +47,15 @@ __global__ void __launch_bounds__(1024) k_probe(float *out, int iters) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int u = 0; u < 16; u++) asm volatile("" : : "v"(r[u]));
-        } else if (MODE == 5 || MODE == 7) {
+        } else if (MODE == 5 || MODE == 7 || MODE == 8 || MODE == 9 || MODE == 10 || MODE == 11) {
             f2 r[16];
 #pragma unroll
             for (int u = 0; u < 16; u++) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r[u]) : "v"(addr), "n"(u * 512));
             if (MODE == 7) asm volatile(REP16("s_add_u32 %0, %0, 1\n") : "+s"(sacc));
+            if (MODE == 8) asm volatile(REP8("s_cmp_eq_u32 %0, %0\n s_cbranch_scc1 1f\n s_add_u32 %0, %0, 1\n 1:\n") : "+s"(sacc) : : "scc");
+            if (MODE == 9) asm volatile(REP8("s_cmp_lg_u32 %0, %0\n s_cbranch_scc1 1f\n s_add_u32 %0, %0, 1\n 1:\n") : "+s"(sacc) : : "scc");
+            if (MODE == 10) asm volatile(REP16("v_cndmask_b32 %0, %0, %1, vcc\n") : "+v"(s) : "v"(v.x) : );
+            if (MODE == 11) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int u = 0; u < 16; u++) {
                 asm volatile("s_waitcnt lgkmcnt(%3)\n v_pk_add_f32 %0, %0, %2\n v_pk_add_f32 %1, %1, %2\n"
@@ -95,5 +102,9 @@ int main() {
     run<4>("ds_read_b64 x16, wait for all", 16, cus, out);
     run<5>("ds_read_b64 x16 + 32 v_pk_add_f32 (counted waits)", 48, cus, out);
     run<7>("the same + 16 s_add_u32", 64, cus, out);
+    run<8>("the same + 8 x (s_cmp, taken s_cbranch)", 64, cus, out);
+    run<9>("the same + 8 x (s_cmp, untaken s_cbranch, s_add)", 72, cus, out);
+    run<10>("the same + 16 v_cndmask_b32", 64, cus, out);
+    run<11>("the same, one wait for all 16 reads before the adds", 48, cus, out);
     return 0;
 }
