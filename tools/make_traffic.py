@@ -2,8 +2,9 @@
 """profiles/traffic.json from the two PMC summaries of tools/gpu_profile.sh:
     tools/make_traffic.py <fetch_summary.txt> <write_summary.txt> <name of the committed copies under profiles/>
 HBM bytes per launch of the aggregation kernel = (2 * FETCH_SIZE + WRITE_SIZE) KiB, mean over the launches that read
-a volume (gfx950 tallies the 128-byte read requests of a wide streaming read at 64 bytes, so the read side is
-doubled; WRITE_SIZE is exact). The file is stamped with a hash of the kernel sources: bench.py reports the figure
+a volume (on this chip FETCH_SIZE reports half of the bytes read, WRITE_SIZE the bytes written exactly: measured on
+kernels that move a known 1 GiB in the volume kernels' access shapes, tools/microbench/pmc_calibration.hip, summary in
+profiles/r03_pmc_calibration.txt). The file is stamped with a hash of the kernel sources: bench.py reports the figure
 only while the sources it runs are the ones the counters were taken on."""
 import json
 import os
