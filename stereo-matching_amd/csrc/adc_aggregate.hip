@@ -737,11 +737,11 @@ __device__ unsigned long long g_agg_stamp[8];
 //   0  every wave brings its own pair of positions by one 16-byte-per-lane LDS-DMA per iteration
 //   1  a loader wave: wave 15 issues the fills of all pairs and the descriptor DMA, waves 0..14 only compute
 //      (30 positions per iteration) and never touch the vector-memory wait counter
-//   2  every wave loads its pair into registers (global_load_dwordx4) and writes it to the ring one iteration later
+// (A third form -- every wave loads its pair into registers with global_load_dwordx4 and writes it to the ring behind
+// stage 2 -- measured the same as mode 0 and was dropped.)
 template <int VEC, bool FULLD, int MODE> struct FusedShape {
     static constexpr bool X4 = FULLD && VEC == 2;
     static constexpr bool LOADER = X4 && MODE == 1;
-    static constexpr bool REGFILL = X4 && MODE == 2;
     static constexpr int CW = LOADER ? AGG_WAVES - 1 : AGG_WAVES;   // computing waves
     static constexpr int B = 2 * CW;                                 // positions per iteration
 };
@@ -757,7 +757,7 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
     constexpr int SLOT = 64 * VEC;
     typedef FusedShape<VEC, FULLD, MODE> Shape;
     constexpr int B = Shape::B, CW = Shape::CW;
-    constexpr bool LOADER = Shape::LOADER, REGFILL = Shape::REGFILL;
+    constexpr bool LOADER = Shape::LOADER;
     extern __shared__ __align__(16) float ring[];   // ring 1 (src): R1 x SLOT, then ring 2 (A): R2 x SLOT
     float *const ring2 = ring + (size_t)R1 * SLOT;
     const int lane = threadIdx.x & 63;
@@ -897,8 +897,6 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
     uint4 d1c = make_uint4(uni(d1v.x), uni(d1v.y), uni(d1v.z), 0u);
     uint32_t d2c = uni(d2v);
     int nstore_prev = 0, sb = 0, sb2 = 2;         // staging buffers: sb holds this iteration's descriptors, sb2 takes the DMA
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    f32x4 freg = {};                               // REGFILL: this iteration's pair on its way to the ring
 
 #ifdef AGG_STAMP
     unsigned long long st[8] = {}, tprev = __builtin_readcyclecounter();
@@ -917,9 +915,7 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
                 ring_fill_x4(src + lbase + (lane & 31) * 4, ring + qf * SLOT);
             } else
 #endif
-            if constexpr (REGFILL) {
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(freg) : "v"(fill_p4 + (fp + 1 < LEN ? second : (ptrdiff_t)0)) : "memory");
-            } else if constexpr (FILL_X4) {
+            if constexpr (FILL_X4) {
                 ring_fill_x4(fill_p4 + (fp + 1 < LEN ? second : (ptrdiff_t)0), ring + qf * SLOT);
             } else {
 #pragma unroll
@@ -950,13 +946,6 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
             desc_windows<VEC>(out0, out1, ro2, R2, q2, d2c);
             nstore = (d2c >> 31) ? 2 : 1;
         }
-        if constexpr (REGFILL) {
-            // the pair loaded at the top of the iteration goes into the ring in front of the stores: the wait is then
-            // for that load (and older operations) only
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(freg) : : "memory");
-            typedef volatile f32x4 __attribute__((address_space(3))) *lds_f4_ptr;
-            *(lds_f4_ptr)(uintptr_t)(ring + qf * SLOT + lane * 4) = freg;
-        }
 #ifdef AGG_DIAG_NO_MEM
         if (nstore && reinterpret_cast<float &>(out0) == -1.f) *reinterpret_cast<vec_t *>(out_p) = out0 + out1;   // (never true)
         nstore = 0;
@@ -971,8 +960,8 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
         //     them the descriptors issued in front of them, which are the next iteration's). Issued since then, in
         //     order: that iteration's stores, this one's descriptor DMA, its fills and its stores -- 2 + 1 + NFILL + 2
         //     operations in the steady state, and never fewer than 1 + NFILL (wave 0; the others issue no descriptor DMA).
-        if constexpr (LOADER || REGFILL) {
-            // (nothing to wait for: the loader wave waits for its fills / the ring write above followed its own wait)
+        if constexpr (LOADER) {
+            // (nothing to wait for: the loader wave waits for its fills)
         } else if constexpr (FULLD) {
             if (wave == 0) {
                 if (nstore == 2 && nstore_prev == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 + NFILL) : "memory");
@@ -1140,7 +1129,6 @@ static hipError_t setup_vec() {
     set(reinterpret_cast<const void *>(&k_agg_fused<VEC, false, 0>), 160 * 1024);
     if (VEC == 2) {
         set(reinterpret_cast<const void *>(&k_agg_fused<2, true, 1>), 160 * 1024);
-        set(reinterpret_cast<const void *>(&k_agg_fused<2, true, 2>), 160 * 1024);
     }
     return e;
 }
@@ -1181,7 +1169,6 @@ void launch_aggregate_fused_pair(const float *src, float *dst, const uint4 *desc
     if (vec == 2) {
         if (!fulld) ADC_FUSED_GO(2, false, 0);
         else if (mode == 1) ADC_FUSED_GO(2, true, 1);
-        else if (mode == 2) ADC_FUSED_GO(2, true, 2);
         else ADC_FUSED_GO(2, true, 0);
     } else { if (fulld) ADC_FUSED_GO(1, true, 0); else ADC_FUSED_GO(1, false, 0); }
 #undef ADC_FUSED_GO

@@ -545,3 +545,16 @@ def test_fused_aggregation_pairs(pkg, orc, synth, monkeypatch, W, H, dmin, dmax,
     aux = h.get_buffer("cost_scan_aux")
     h.close()
     assert same(disp, got["disp_final"]) and same(vol, got["cost_scan"]) and same(aux, got["cost_scan_aux"])
+
+
+@pytest.mark.parametrize("mode", ["0", "1"])
+@pytest.mark.parametrize("W,H,dmin,dmax", [(200, 120, 0, 256), (61, 150, -3, 125), (33, 35, 0, 128)])
+def test_fused_aggregation_fill_modes(pkg, orc, synth, monkeypatch, mode, W, H, dmin, dmax):
+    """Full 128-float ring slots (D a multiple of 128): ring 1 of the fused aggregation launch is filled either by every
+    wave for itself (ADC_AGG_MODE=0) or by a loader wave beside fifteen computing waves (1, the default; 30 positions per
+    iteration instead of 32, other ring sizes). Both are the oracle's bits, lines shorter than one iteration included."""
+    monkeypatch.setenv("ADC_DEBUG_ENV", "1")
+    monkeypatch.setenv("ADC_AGG_MODE", mode)
+    L, R, _ = synth.pair(190, max(W, 16), max(H, 16), dmax - dmin)
+    L, R = np.ascontiguousarray(L[:H, :W]), np.ascontiguousarray(R[:H, :W])
+    check_against_oracle(pkg, orc, L, R, min_disparity=dmin, max_disparity=dmax)

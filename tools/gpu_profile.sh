@@ -20,7 +20,7 @@ timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_
 cd "$root"
 python tools/pmc_summary.py "$out/pmc_fetch" > "$out/pmc_fetch_summary.txt"
 python tools/pmc_summary.py "$out/pmc_write" > "$out/pmc_write_summary.txt"
-python tools/make_traffic.py "$out/pmc_fetch_summary.txt" "$out/pmc_write_summary.txt" "profiles/${tag}_pmc_fetch_size.txt, profiles/${tag}_pmc_write_size.txt" || exit 1
+python tools/make_traffic.py "$out/pmc_fetch_summary.txt" "$out/pmc_write_summary.txt" "profiles/${tag}_pmc_fetch_summary.txt, profiles/${tag}_pmc_write_summary.txt" || exit 1
 cp profiles/traffic.json "$out/traffic.json"
 find "$out/kt" -name '*kernel_stats.csv' -exec cp {} "$out/kernel_stats.csv" \;
 # per-launch durations of the volume kernels of one match, in launch order (from the trace, before it is deleted)
