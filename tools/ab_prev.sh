@@ -1,3 +1,4 @@
+# (lib/variants/libadc_prev.so = the library with csrc/adc_aggregate.hip of the previous commit, built like tools/build_variant.sh does)
 # parity of the current build on the fused-aggregation shapes, then timing against lib/variants/libadc_prev.so (alternating)
 set -o pipefail
 mkdir -p gpurun_out/ab
