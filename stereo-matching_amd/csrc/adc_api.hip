@@ -382,9 +382,9 @@ int enqueue_match(adc_handle *h, const uint8_t *d_l, const uint8_t *d_r, float *
     launch_census(pl.gray_l, pl.gray_r, pl.cen_l, pl.cen_r, g.W, g.H, s);
     launch_step_flags(pl.pix_l, pl.pix_r, pl.step_l, pl.step_r, g.W, g.H, o.so_tso, s);
     launch_arms(pl.pix_l, pl.arms, g.W, g.H, o.cross_L1, o.cross_L2, o.cross_t1, o.cross_t2, s);
-    launch_sup_counts(pl.arms, pl.cnt_h, pl.cnt_v, pl.cnt_h32, pl.cnt_v32, g.W, g.H, s);
-    launch_scan_records(pl, g, s);
     const int cap = max_arm_of(o);
+    launch_sup_counts(pl.arms, pl.cnt_h, pl.cnt_v, pl.cnt_h32, pl.cnt_v32, g.W, g.H, cap, s);
+    launch_scan_records(pl, g, s);
     const bool fuse_pairs = h->tune.agg_variant == 0 && aggregate_pair_fusion_supported(g, cap);
     // horizontal dividing passes divide by the vertical-first counts, vertical ones by the horizontal-first counts
     if (fuse_pairs) launch_pair_descriptors(pl.arms, pl.cnt_v32, pl.cnt_h32, pl.pair_h, pl.pair_v, g, cap, s);

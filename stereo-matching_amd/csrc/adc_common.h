@@ -67,8 +67,9 @@ void launch_census(const uint8_t *gray_l, const uint8_t *gray_r, uint32_t *censu
 void launch_step_flags(const uint32_t *pix_l, const uint32_t *pix_r, uint8_t *flags_l, uint8_t *flags_r, int W, int H,
                        int tso, hipStream_t s);
 void launch_arms(const uint32_t *pix, uint32_t *arms, int W, int H, int L1, int L2, int t1, int t2, hipStream_t s);
+// cap: the arm length cap the arms were built with (min(cross_L1, 255), not negative)
 void launch_sup_counts(const uint32_t *arms, uint16_t *cnt_h, uint16_t *cnt_v, uint32_t *cnt_h32, uint32_t *cnt_v32,
-                       int W, int H, hipStream_t s);
+                       int W, int H, int cap, hipStream_t s);
 void launch_cost_init(const Planes &p, const Geom &g, const float *lut_ad, const float *lut_cen,
                       float *cost, hipStream_t s);
 void launch_census_to_u64(const uint32_t *c32, uint64_t *c64, size_t n, hipStream_t s);
