@@ -114,8 +114,12 @@ hipError_t launch_clear_masks(uint8_t *occ, uint8_t *mis, uint32_t *counters, si
 // ---- iterative region voting (RegionVotingCuda + DeleteFilledPixel, ADC/multistep_refiner.cu:376-449)
 // One wavefront (= one 64-thread workgroup) per listed pixel: the disparity histogram of the cross
 // support region is built in LDS. The arms of up to 64 region rows are fetched with one load (lane <->
-// row); each row's horizontal span is then read with lanes along the row, VOTE_ROWS rows per batch so
-// that their loads are in flight together instead of one dependent round trip per row.
+// row). A region row is at most 2*cap + 1 pixels long, far fewer than a wave has lanes, so one wave
+// instruction serves SEVERAL rows: a lane reads VOTE_PX neighbouring pixels of the histogram-bin map with
+// one (unaligned) 16-byte load, ceil((2*cap + 1) / VOTE_PX) lanes cover a row, and as many rows as fit
+// into 64 lanes share every load and every histogram update (seven rows for the default cap of 34). The
+// kernel is bound by the instructions it issues per region row, not by bytes. Counts are integers: the
+// order in which a region's pixels reach the histogram does not matter.
 //
 // A pixel that failed the vote fails it again for as long as no disparity inside its support region has
 // changed, so from a list's second pass on the histogram is rebuilt only for pixels that had a fill
@@ -124,11 +128,14 @@ hipError_t launch_clear_masks(uint8_t *occ, uint8_t *mis, uint32_t *counters, si
 // region (its own vertical arms, the arm cap horizontally) carries a stamp from the two passes since
 // its previous turn. Stamps grow monotonically over frames (stamp0 = this frame's pass 0), so the tile
 // array is never cleared.
-#define VOTE_ROWS 8
-// Most pixels of a support region carry the same one or two disparities, so the 64 lanes of a histogram
+#define VOTE_PX 8
+#ifndef VOTE_GROUPS
+#define VOTE_GROUPS 4   // loads in flight per lane
+#endif
+// Most pixels of a support region carry the same one or two disparities, so the lanes of a histogram
 // update mostly hit one LDS word and are served one after the other. VOTE_COPIES histograms, one per
 // lane & (VOTE_COPIES - 1), with an odd stride (different banks for the same bin) cut that serialisation;
-// the copies are summed when the histogram is read out. Counts are integers: any order is exact.
+// the copies are summed when the histogram is read out.
 #ifndef VOTE_COPIES
 #define VOTE_COPIES 4
 #endif
@@ -138,14 +145,21 @@ hipError_t launch_clear_masks(uint8_t *occ, uint8_t *mis, uint32_t *counters, si
 #ifndef VOTE_SKIP_FROM
 #define VOTE_SKIP_FROM 2
 #endif
+static size_t vote_lds_bytes(int D) { return (((size_t)VOTE_COPIES * (D | 1) + 3) & ~(size_t)3) * sizeof(int); }
 __global__ void __launch_bounds__(64)
 k_vote(const float *__restrict__ disp, const short *__restrict__ binmap, const uint8_t *__restrict__ mask,
        const uint32_t *__restrict__ list, const uint32_t *__restrict__ count, float *__restrict__ newval,
        const uint32_t *__restrict__ arms, const uint32_t *__restrict__ tile_stamp, int W, int dmin, int D,
        int tau_s, float tau_h, int cap, int tiles_w, uint32_t stamp0, int pass) {
-    extern __shared__ int hist[];
+    extern __shared__ __align__(16) int hist[];
     const int lane = threadIdx.x;
     const int hstride = D | 1, hcopy = (lane & (VOTE_COPIES - 1)) * hstride;
+    const int hquads = (VOTE_COPIES * hstride + 3) >> 2;
+    // lane <-> (row slot, pixel group) of a wave instruction
+    const int lpr = (2 * cap + 1 + VOTE_PX - 1) / VOTE_PX;     // lanes per region row (<= 64: cap <= 255)
+    const int rpi = 64 / lpr;                                  // region rows per wave instruction
+    const int rslot = lane / lpr, grp = lane - rslot * lpr;
+    const bool lane_on = rslot < rpi;
     const uint32_t n = *count;
     for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
         const uint32_t p = list[e];
@@ -168,7 +182,7 @@ k_vote(const float *__restrict__ disp, const short *__restrict__ binmap, const u
             }
         }
         if (todo) {
-            for (int k = lane; k < VOTE_COPIES * hstride; k += 64) hist[k] = 0;
+            for (int k = lane; k < hquads; k += 64) reinterpret_cast<int4 *>(hist)[k] = make_int4(0, 0, 0, 0);
             __syncthreads();
             const int top = (a >> 16) & 0xff, bot = a >> 24;
             const int nrows = top + bot + 1;
@@ -177,66 +191,57 @@ k_vote(const float *__restrict__ disp, const short *__restrict__ binmap, const u
                 const size_t qrow = (size_t)p + (ptrdiff_t)(r0 - top) * W;    // first row of this chunk
                 uint32_t arow = 0;
                 if (lane < nr) arow = arms[qrow + (size_t)lane * W];
-                // settle the load here: otherwise every v_readlane of arow below is preceded by a full
+                // settle the load here: otherwise every cross-lane read of arow below is preceded by a full
                 // vmcnt(0), which also waits for the row loads just issued and serialises them
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(arow));
-                for (int t0 = 0; t0 < nr; t0 += VOTE_ROWS) {
-                    // a lane reads two neighbouring pixels of a row with one (possibly unaligned) 4-byte load: the
-                    // vector cache's address path is what limits this loop, and half as many lanes issue a load
-                    uint32_t bw[VOTE_ROWS], bw2[VOTE_ROWS];
-                    int sp[VOTE_ROWS];
-                    bool any_b = false;
+                for (int t0 = 0; t0 < nr; t0 += rpi * VOTE_GROUPS) {
+                    uint4 bw[VOTE_GROUPS];
+                    int last[VOTE_GROUPS];          // this lane's pixels 0 .. last of the load are inside the row's span
+                    uint32_t a2[VOTE_GROUPS];
 #pragma unroll
-                    for (int u = 0; u < VOTE_ROWS; u++) {
-                        bw[u] = 0xffffffffu;
-                        bw2[u] = 0xffffffffu;
-                        sp[u] = -1;
-                        if (t0 + u < nr) {                                   // uniform
-                            const uint32_t a2 = __builtin_amdgcn_readlane(arow, t0 + u);
-                            const int l2 = a2 & 0xff, r2 = (a2 >> 8) & 0xff;
-                            const short *row = binmap + qrow + (size_t)(t0 + u) * W - l2;
-                            const int span = l2 + r2;                        // pixels 0 .. span
-                            sp[u] = span;
-                            if (2 * lane <= span) bw[u] = *reinterpret_cast<const uint32_t *>(row + 2 * lane);
-                            if (span >= 128) {                               // uniform, spans longer than 128 pixels
-                                any_b = true;
-                                if (2 * lane + 128 <= span) bw2[u] = *reinterpret_cast<const uint32_t *>(row + 2 * lane + 128);
-                            }
+                    for (int u = 0; u < VOTE_GROUPS; u++)                    // (rows past the region read a zero or a stale arm: unused)
+                        a2[u] = (uint32_t)__shfl((int)arow, (t0 + u * rpi + rslot) & 63, 64);
+#pragma unroll
+                    for (int u = 0; u < VOTE_GROUPS; u++) {
+                        last[u] = -1;
+                        bw[u] = make_uint4(0u, 0u, 0u, 0u);
+                        const int r = t0 + u * rpi + rslot;
+                        const int l2 = a2[u] & 0xff, r2 = (a2[u] >> 8) & 0xff;
+                        if (lane_on && r < nr) last[u] = l2 + r2 - VOTE_PX * grp;
+                        if (last[u] >= 0) {
+                            const short *src = binmap + qrow + (size_t)r * W - l2 + VOTE_PX * grp;
+                            __builtin_memcpy(&bw[u], src, 16);               // (2-byte aligned)
                         }
                     }
 #pragma unroll
-                    for (int u = 0; u < VOTE_ROWS; u++) {
-                        const int lo = (short)(bw[u] & 0xffffu), hi = (short)(bw[u] >> 16);
-                        if (2 * lane <= sp[u] && lo >= 0) atomicAdd(&hist[hcopy + lo], 1);
-                        if (2 * lane + 1 <= sp[u] && hi >= 0) atomicAdd(&hist[hcopy + hi], 1);
-                    }
-                    if (any_b) {
+                    for (int u = 0; u < VOTE_GROUPS; u++) {
+                        const uint32_t w[4] = {bw[u].x, bw[u].y, bw[u].z, bw[u].w};
 #pragma unroll
-                        for (int u = 0; u < VOTE_ROWS; u++) {
-                            const int lo = (short)(bw2[u] & 0xffffu), hi = (short)(bw2[u] >> 16);
-                            if (2 * lane + 128 <= sp[u] && lo >= 0) atomicAdd(&hist[hcopy + lo], 1);
-                            if (2 * lane + 129 <= sp[u] && hi >= 0) atomicAdd(&hist[hcopy + hi], 1);
+                        for (int k = 0; k < VOTE_PX; k++) {
+                            const int b = (short)(k & 1 ? w[k >> 1] >> 16 : w[k >> 1] & 0xffffu);
+                            if (k <= last[u] && b >= 0) atomicAdd(&hist[hcopy + b], 1);
                         }
                     }
                 }
             }
             __syncthreads();
-            // first bin holding the maximum count, and the total
-            int mh = 0, mk = 0x7fffffff, cnt = 0;
+            // first bin holding the maximum count, and the total: the maximum of (count << 9 | 511 - bin) over the
+            // bins with a count (counts stay below 2^18, bins below 512)
+            uint32_t key = 0;
+            int cnt = 0;
             for (int k = lane; k < D; k += 64) {
                 int h = hist[k];
 #pragma unroll
                 for (int c = 1; c < VOTE_COPIES; c++) h += hist[c * hstride + k];
-                if (mh < h) { mh = h; mk = k; }
+                if (h > 0) key = max(key, (uint32_t)h << 9 | (uint32_t)(511 - k));
                 cnt += h;
             }
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) {
-                const int oh = __shfl_xor(mh, off, 64);
-                const int ok = __shfl_xor(mk, off, 64);
+                key = max(key, (uint32_t)__shfl_xor((int)key, off, 64));
                 cnt += __shfl_xor(cnt, off, 64);
-                if (oh > mh || (oh == mh && ok < mk)) { mh = oh; mk = ok; }
             }
+            const int mh = (int)(key >> 9), mk = 511 - (int)(key & 511u);
             if (mh > 0) {
                 if (cnt > tau_s && mh * 1.0f / cnt > tau_h) result = mk + (float)dmin;
             }
@@ -300,7 +305,7 @@ void launch_region_voting_pass(float *disp, short *binmap, uint8_t *mask, const 
                                float *newval, const uint32_t *arms, uint32_t *tile_stamp, uint32_t stamp0, int pass,
                                int cap, const Geom &g, int tau_s, float tau_h, hipStream_t s) {
     const int tw = vote_tiles_w(g.W);
-    k_vote<<<dim3(8192), dim3(64), (size_t)VOTE_COPIES * (g.D | 1) * sizeof(int), s>>>(disp, binmap, mask, list, count, newval, arms,
+    k_vote<<<dim3(8192), dim3(64), vote_lds_bytes(g.D), s>>>(disp, binmap, mask, list, count, newval, arms,
                                                                   tile_stamp, g.W, g.dmin, g.D, tau_s, tau_h, cap, tw,
                                                                   stamp0, pass);
     k_apply<<<dim3(512), dim3(256), 0, s>>>(disp, binmap, mask, list, count, newval, out_list, out_count, tile_stamp,
