@@ -241,7 +241,7 @@ int do_initialize(adc_handle *h, int32_t W, int32_t H, const adc_option *opt, hi
     A(h->list3_mis, npx); A(h->list3_occ, npx);
     A(h->newval, 2 * npx);
     A(h->binmap, npx);
-    A(h->tile_stamp, (size_t)vote_tiles_w(W) * vote_tiles_h(H));
+    A(h->tile_stamp, (size_t)vote_tiles_w(W) * vote_tiles_h(H) + 1);   // + a word that stays zero (read by lanes with no tile)
     if (!in_arena) A(h->tap_u64, npx);
     // ray tables of the 16-direction search: m*sin, m*cos (double) and, when usable, their rounded offsets
     const int maxlen = std::abs(opt->max_disparity) * 1;  // MaxSearchLengthTimes = 1 (ADC/config.h:24)
@@ -257,7 +257,7 @@ int do_initialize(adc_handle *h, int32_t W, int32_t H, const adc_option *opt, hi
     // padding columns of the volumes are never produced by the cost kernel; give them a defined value once
     HIPCHK(h, hipMemsetAsync(h->vol_a, 0, nvol * sizeof(float), s0));
     HIPCHK(h, hipMemsetAsync(h->vol_b, 0, nvol * sizeof(float), s0));
-    HIPCHK(h, hipMemsetAsync(h->tile_stamp, 0, (size_t)vote_tiles_w(W) * vote_tiles_h(H) * sizeof(uint32_t), s0));
+    HIPCHK(h, hipMemsetAsync(h->tile_stamp, 0, ((size_t)vote_tiles_w(W) * vote_tiles_h(H) + 1) * sizeof(uint32_t), s0));
     h->vote_stamp = 16;
     // the padding records in front of and behind every line of the pair descriptors stay zero for good
     HIPCHK(h, hipMemsetAsync(h->pl.pair_h, 0, n_pair_h * sizeof(uint4), s0));
@@ -481,7 +481,7 @@ int enqueue_match(adc_handle *h, const uint8_t *d_l, const uint8_t *d_r, float *
     SNAP(h->snap_mis, h->mis, npx);
     if (o.do_filling) {  // drives both voting and interpolation (ADC/ADCensusStereo.cu:195-196)
         if (h->vote_stamp > 0xffffff00u) {   // stamps would wrap: start over
-            EQ(hipMemsetAsync(h->tile_stamp, 0, (size_t)vote_tiles_w(g.W) * vote_tiles_h(g.H) * sizeof(uint32_t), s));
+            EQ(hipMemsetAsync(h->tile_stamp, 0, ((size_t)vote_tiles_w(g.W) * vote_tiles_h(g.H) + 1) * sizeof(uint32_t), s));
             h->vote_stamp = 16;
         }
         const uint32_t stamp0 = h->vote_stamp;

@@ -130,109 +130,203 @@ hipError_t launch_clear_masks(uint8_t *occ, uint8_t *mis, uint32_t *counters, si
 // array is never cleared.
 #define VOTE_PX 8
 #ifndef VOTE_GROUPS
-#define VOTE_GROUPS 4   // loads in flight per lane
+#define VOTE_GROUPS 2   // loads in flight per lane
 #endif
 // Most pixels of a support region carry the same one or two disparities, so the lanes of a histogram
-// update mostly hit one LDS word and are served one after the other. VOTE_COPIES histograms, one per
-// lane & (VOTE_COPIES - 1), with an odd stride (different banks for the same bin) cut that serialisation;
-// the copies are summed when the histogram is read out.
+// update mostly hit one LDS word and are served one after the other. Every bin therefore has VOTE_COPIES
+// counters, one per lane & (VOTE_COPIES - 1), next to each other (16 bytes per bin: four different banks,
+// one ds_read_b128 when the histogram is read out); they are summed at the read-out. (Eight or sixteen
+// counters per bin measured slower: fewer workgroups fit a CU.)
+// LDS layout in bytes: [0, VOTE_BINB) the words "bin -1" (no valid disparity, or past the end of the row's
+// span) maps to -- never updated, only addressed --, then VOTE_BINB bytes per bin, then nine 16-byte masks.
 #ifndef VOTE_COPIES
 #define VOTE_COPIES 4
 #endif
+#define VOTE_BINB (4 * VOTE_COPIES)            // bytes per bin
+#define VOTE_LUT(D) (VOTE_BINB + VOTE_BINB * (D))
 #ifndef VOTE_TILE_SHIFT
 #define VOTE_TILE_SHIFT 3
 #endif
 #ifndef VOTE_SKIP_FROM
 #define VOTE_SKIP_FROM 2
 #endif
-static size_t vote_lds_bytes(int D) { return (((size_t)VOTE_COPIES * (D | 1) + 3) & ~(size_t)3) * sizeof(int); }
+static size_t vote_lds_bytes(int D) { return (size_t)VOTE_LUT(D) + 9 * 16; }
+// The loads of a list entry depend on each other: list -> the pixel's arms, mask and disparity -> the arms of its
+// region rows and the stamps of its tiles -> the bin map. Taken one after the other they cost four or five trips
+// to memory per pixel, and a wave does little else. The loop is therefore a software pipeline over the entries of
+// a workgroup, each level issued one iteration ahead of the next:
+//   A  entry i+3: its pixel index                     B  entry i+2: arms, mask and disparity of the pixel
+//   C  entry i+1: arms of its (first 64) region rows and, from the third pass on, its tile stamps
+//   P  entry i:   the vote
+// The loads of A, B and C are issued unconditionally (addresses clamped to valid ones) between the first bin-map
+// loads of P and the histogram updates that wait for them, so that a wait counts loads and never drains them.
+// A workgroup is one wave: LDS operations of one wave execute in order, no barrier is needed.
 __global__ void __launch_bounds__(64)
 k_vote(const float *__restrict__ disp, const short *__restrict__ binmap, const uint8_t *__restrict__ mask,
        const uint32_t *__restrict__ list, const uint32_t *__restrict__ count, float *__restrict__ newval,
        const uint32_t *__restrict__ arms, const uint32_t *__restrict__ tile_stamp, int W, int dmin, int D,
-       int tau_s, float tau_h, int cap, int tiles_w, uint32_t stamp0, int pass) {
-    extern __shared__ __align__(16) int hist[];
+       int tau_s, float tau_h, int cap, int tiles_w, int tiles_n, uint32_t stamp0, int pass) {
+    extern __shared__ __align__(16) unsigned char vote_lds[];
     const int lane = threadIdx.x;
-    const int hstride = D | 1, hcopy = (lane & (VOTE_COPIES - 1)) * hstride;
-    const int hquads = (VOTE_COPIES * hstride + 3) >> 2;
+    int4 *const hist4 = reinterpret_cast<int4 *>(vote_lds + VOTE_BINB);    // VOTE_COPIES counters per bin
+    // byte offset (an LDS address) of this lane's counter of bin 0
+    const uint32_t hbase = (uint32_t)(uintptr_t)(vote_lds + VOTE_BINB) + 4u * (uint32_t)(lane & (VOTE_COPIES - 1));
+    const uint32_t lut_off = (uint32_t)(uintptr_t)(vote_lds + VOTE_LUT(D));
+    // mask c (c = 0 .. 8): all ones in the 16-bit fields of the pixels c .. 7 of a load (ORed in, they become bin -1)
+    if (lane < 9) {
+        uint32_t m[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) m[j] = (2 * j >= lane ? 0xffffu : 0u) | (2 * j + 1 >= lane ? 0xffff0000u : 0u);
+        reinterpret_cast<uint4 *>(vote_lds + VOTE_LUT(D))[lane] = make_uint4(m[0], m[1], m[2], m[3]);
+    }
     // lane <-> (row slot, pixel group) of a wave instruction
     const int lpr = (2 * cap + 1 + VOTE_PX - 1) / VOTE_PX;     // lanes per region row (<= 64: cap <= 255)
     const int rpi = 64 / lpr;                                  // region rows per wave instruction
     const int rslot = lane / lpr, grp = lane - rslot * lpr;
     const bool lane_on = rslot < rpi;
-    const uint32_t n = *count;
-    for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
-        const uint32_t p = list[e];
-        float result = ADC_INF;
-        bool todo = mask[p] && disp[p] == ADC_INF;   // uniform across the wave
-        uint32_t a = 0;
-        if (todo) {
-            a = arms[p];
-            if (pass >= VOTE_SKIP_FROM) {
-                const int y = (int)(p / (uint32_t)W), x = (int)(p - (uint32_t)y * (uint32_t)W);
+    const uint32_t n = *count, G = gridDim.x, base = blockIdx.x;
+    if (base >= n) return;
+    const uint32_t mine = (n - base + G - 1) / G;              // entries of this workgroup
+    const bool skip = pass >= VOTE_SKIP_FROM;
+    const uint32_t fresh_from = stamp0 + (uint32_t)(pass - 2); // (> 0: stamps start above 2)
+
+    // pipeline registers (B: pB; C: pC, aC, mC, dC; P: pP, aP, mP, dP, arow, st0, st1, ntP)
+    uint32_t pB = 0, pC = 0, aC = 0, pP = 0, aP = 0, arow = 0, st0 = 0, st1 = 0;
+    uint32_t mC = 0, mP = 0;
+    float dC = 0.0f, dP = 0.0f;
+    int ntP = 0;
+    for (uint32_t it = 0; it < mine + 3; it++) {
+        // ---- P, first half: the decision, the cleared histogram and the first bin-map loads
+        const bool vP = it >= 3;                               // (it - 3 < mine by the loop bound)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(arow), "+v"(st0), "+v"(st1));   // settled here, not in front of every cross-lane read
+        bool todo = vP && mP != 0u && dP == ADC_INF;           // uniform across the wave
+        if (todo && skip) {
+            bool fresh = st0 >= fresh_from || st1 >= fresh_from;
+            if (ntP > 128) {                                   // (arm caps beyond 34: more tiles than two loads per lane cover)
+                const int y = (int)(pP / (uint32_t)W), x = (int)(pP - (uint32_t)y * (uint32_t)W);
                 const int tx0 = max(x - cap, 0) >> VOTE_TILE_SHIFT, tx1 = min(x + cap, W - 1) >> VOTE_TILE_SHIFT;
-                const int ty0 = (y - (int)((a >> 16) & 0xff)) >> VOTE_TILE_SHIFT, ty1 = (y + (int)(a >> 24)) >> VOTE_TILE_SHIFT;
-                const int ntx = tx1 - tx0 + 1, nt = ntx * (ty1 - ty0 + 1);
-                bool fresh = false;
-                for (int t = lane; t < nt; t += 64) {
+                const int ty0 = (y - (int)((aP >> 16) & 0xff)) >> VOTE_TILE_SHIFT;
+                const int ntx = tx1 - tx0 + 1;
+                for (int t = lane + 128; t < ntP; t += 64) {
                     const int ty = ty0 + t / ntx, tx = tx0 + t % ntx;
-                    fresh |= tile_stamp[ty * tiles_w + tx] >= stamp0 + (uint32_t)(pass - 2);
+                    fresh |= tile_stamp[ty * tiles_w + tx] >= fresh_from;
                 }
-                todo = __ballot(fresh) != 0ull;
+            }
+            todo = __ballot(fresh) != 0ull;
+        }
+        const int top = (aP >> 16) & 0xff, bot = aP >> 24;
+        const int nrows = top + bot + 1;
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        uint4 bw[VOTE_GROUPS];
+        u32x4 bm[VOTE_GROUPS];
+        int last[VOTE_GROUPS];              // this lane's pixels 0 .. last of the load are inside the row's span
+        // the loads of region rows t0 .. t0 + rpi*VOTE_GROUPS - 1 of a chunk of nr rows starting at pixel qrow
+        auto issue = [&](uint32_t ar, size_t qrow, int t0, int nr) {
+            uint32_t a2[VOTE_GROUPS];
+#pragma unroll
+            for (int u = 0; u < VOTE_GROUPS; u++)              // (rows past the region read a zero or a stale arm: unused)
+                a2[u] = (uint32_t)__shfl((int)ar, (t0 + u * rpi + rslot) & 63, 64);
+#pragma unroll
+            for (int u = 0; u < VOTE_GROUPS; u++) {
+                last[u] = -1;
+                bw[u] = make_uint4(0u, 0u, 0u, 0u);
+                const int r = t0 + u * rpi + rslot;
+                const int l2 = a2[u] & 0xff, r2 = (a2[u] >> 8) & 0xff;
+                if (lane_on && r < nr) last[u] = l2 + r2 - VOTE_PX * grp;
+                if (last[u] >= 0) {
+                    const short *src = binmap + qrow + (size_t)r * W - l2 + VOTE_PX * grp;
+                    __builtin_memcpy(&bw[u], src, 16);         // (2-byte aligned)
+                }
+                typedef const u32x4 __attribute__((address_space(3))) *lut_ptr;
+                bm[u] = *(lut_ptr)(uintptr_t)(lut_off + 16u * (uint32_t)min(max(last[u] + 1, 0), VOTE_PX));
+            }
+        };
+        // One histogram update per pixel and nothing else: the LDS address of a pixel's counter is one v_mad_i32_i16
+        // (16 * bin + this lane's base, the bin taken from either half of the loaded word), and pixels that do not
+        // count carry bin -1, whose counters are the four spare words in front of bin 0. Lanes with no pixel of the
+        // row at all are switched off for the whole load.
+        auto update = [&]() {
+            typedef int __attribute__((address_space(3))) *cnt_ptr;
+#pragma unroll
+            for (int u = 0; u < VOTE_GROUPS; u++) {
+                if (last[u] >= 0) {
+                    const uint32_t w[4] = {bw[u].x | bm[u].x, bw[u].y | bm[u].y, bw[u].z | bm[u].z, bw[u].w | bm[u].w};
+#pragma unroll
+                    for (int k = 0; k < VOTE_PX; k++) {
+                        uint32_t addr;
+                        if (k & 1) asm("v_mad_i32_i16 %0, %1, %3, %2 op_sel:[1,0,0,0]" : "=v"(addr) : "v"(w[k >> 1]), "v"(hbase), "n"(VOTE_BINB));
+                        else asm("v_mad_i32_i16 %0, %1, %3, %2" : "=v"(addr) : "v"(w[k >> 1]), "v"(hbase), "n"(VOTE_BINB));
+                        // (pixels that do not count are switched off; counting them on the spare words instead is cheaper
+                        //  to issue but slower: every such lane then queues at the same four words)
+                        if ((int)addr >= (int)hbase)
+                        __hip_atomic_fetch_add((cnt_ptr)(uintptr_t)addr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+        };
+        const size_t qrow0 = (size_t)pP - (size_t)top * W;     // first row of the region
+        const int nr0 = min(64, nrows);
+        if (todo) {
+            for (int k = lane; k < D * (VOTE_COPIES / 4); k += 64) hist4[k] = make_int4(0, 0, 0, 0);
+            issue(arow, qrow0, 0, nr0);
+        }
+
+        // ---- A, B, C of the entries behind P (addresses of entries past the end are clamped: loaded, never used)
+        const uint32_t nA = list[min(base + it * G, n - 1)];
+        const uint32_t naB = arms[pB];
+        // (the mask byte through the aligned word around it: a uniform dword load goes to the scalar unit like its
+        //  neighbours; every buffer has slack behind its last element)
+        const uint32_t nmB = (reinterpret_cast<const uint32_t *>(mask)[pB >> 2] >> (8u * (pB & 3u))) & 0xffu;
+        const float ndB = disp[pB];
+        uint32_t narow, nst0 = 0, nst1 = 0;
+        int nntC = 0;
+        {
+            const int topC = (aC >> 16) & 0xff, botC = aC >> 24;
+            const int nrC = min(64, topC + botC + 1);
+            narow = arms[(size_t)pC + (ptrdiff_t)(min(lane, nrC - 1) - topC) * W];
+            if (skip) {
+                const int y = (int)(pC / (uint32_t)W), x = (int)(pC - (uint32_t)y * (uint32_t)W);
+                const int tx0 = max(x - cap, 0) >> VOTE_TILE_SHIFT, tx1 = min(x + cap, W - 1) >> VOTE_TILE_SHIFT;
+                const int ty0 = (y - topC) >> VOTE_TILE_SHIFT, ty1 = (y + botC) >> VOTE_TILE_SHIFT;
+                const int ntx = tx1 - tx0 + 1;
+                nntC = ntx * (ty1 - ty0 + 1);
+                // lanes past the last tile read the zero word behind the stamps (tiles_n): never fresh
+                const int t0 = lane, t1 = lane + 64;
+                nst0 = tile_stamp[t0 < nntC ? (ty0 + t0 / ntx) * tiles_w + tx0 + t0 % ntx : tiles_n];
+                nst1 = tile_stamp[t1 < nntC ? (ty0 + t1 / ntx) * tiles_w + tx0 + t1 % ntx : tiles_n];
             }
         }
+
+        // ---- P, second half
+        float result = ADC_INF;
         if (todo) {
-            for (int k = lane; k < hquads; k += 64) reinterpret_cast<int4 *>(hist)[k] = make_int4(0, 0, 0, 0);
-            __syncthreads();
-            const int top = (a >> 16) & 0xff, bot = a >> 24;
-            const int nrows = top + bot + 1;
-            for (int r0 = 0; r0 < nrows; r0 += 64) {
+            update();
+            for (int t0 = rpi * VOTE_GROUPS; t0 < nr0; t0 += rpi * VOTE_GROUPS) {
+                issue(arow, qrow0, t0, nr0);
+                update();
+            }
+            for (int r0 = 64; r0 < nrows; r0 += 64) {          // regions taller than 64 rows
                 const int nr = min(64, nrows - r0);
-                const size_t qrow = (size_t)p + (ptrdiff_t)(r0 - top) * W;    // first row of this chunk
-                uint32_t arow = 0;
-                if (lane < nr) arow = arms[qrow + (size_t)lane * W];
-                // settle the load here: otherwise every cross-lane read of arow below is preceded by a full
-                // vmcnt(0), which also waits for the row loads just issued and serialises them
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(arow));
+                const size_t qrow = qrow0 + (size_t)r0 * W;
+                uint32_t ar = 0;
+                if (lane < nr) ar = arms[qrow + (size_t)lane * W];
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(ar));
                 for (int t0 = 0; t0 < nr; t0 += rpi * VOTE_GROUPS) {
-                    uint4 bw[VOTE_GROUPS];
-                    int last[VOTE_GROUPS];          // this lane's pixels 0 .. last of the load are inside the row's span
-                    uint32_t a2[VOTE_GROUPS];
-#pragma unroll
-                    for (int u = 0; u < VOTE_GROUPS; u++)                    // (rows past the region read a zero or a stale arm: unused)
-                        a2[u] = (uint32_t)__shfl((int)arow, (t0 + u * rpi + rslot) & 63, 64);
-#pragma unroll
-                    for (int u = 0; u < VOTE_GROUPS; u++) {
-                        last[u] = -1;
-                        bw[u] = make_uint4(0u, 0u, 0u, 0u);
-                        const int r = t0 + u * rpi + rslot;
-                        const int l2 = a2[u] & 0xff, r2 = (a2[u] >> 8) & 0xff;
-                        if (lane_on && r < nr) last[u] = l2 + r2 - VOTE_PX * grp;
-                        if (last[u] >= 0) {
-                            const short *src = binmap + qrow + (size_t)r * W - l2 + VOTE_PX * grp;
-                            __builtin_memcpy(&bw[u], src, 16);               // (2-byte aligned)
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < VOTE_GROUPS; u++) {
-                        const uint32_t w[4] = {bw[u].x, bw[u].y, bw[u].z, bw[u].w};
-#pragma unroll
-                        for (int k = 0; k < VOTE_PX; k++) {
-                            const int b = (short)(k & 1 ? w[k >> 1] >> 16 : w[k >> 1] & 0xffffu);
-                            if (k <= last[u] && b >= 0) atomicAdd(&hist[hcopy + b], 1);
-                        }
-                    }
+                    issue(ar, qrow, t0, nr);
+                    update();
                 }
             }
-            __syncthreads();
             // first bin holding the maximum count, and the total: the maximum of (count << 9 | 511 - bin) over the
             // bins with a count (counts stay below 2^18, bins below 512)
             uint32_t key = 0;
             int cnt = 0;
             for (int k = lane; k < D; k += 64) {
-                int h = hist[k];
+                int h = 0;
 #pragma unroll
-                for (int c = 1; c < VOTE_COPIES; c++) h += hist[c * hstride + k];
+                for (int c = 0; c < VOTE_COPIES / 4; c++) {
+                    const int4 h4 = hist4[k * (VOTE_COPIES / 4) + c];
+                    h += (h4.x + h4.y) + (h4.z + h4.w);
+                }
                 if (h > 0) key = max(key, (uint32_t)h << 9 | (uint32_t)(511 - k));
                 cnt += h;
             }
@@ -245,9 +339,13 @@ k_vote(const float *__restrict__ disp, const short *__restrict__ binmap, const u
             if (mh > 0) {
                 if (cnt > tau_s && mh * 1.0f / cnt > tau_h) result = mk + (float)dmin;
             }
-            __syncthreads();
         }
-        if (lane == 0) newval[e] = result;
+        if (vP && lane == 0) newval[base + (it - 3) * G] = result;
+
+        // ---- every entry moves up one level
+        pP = pC; aP = aC; mP = mC; dP = dC; arow = narow; st0 = nst0; st1 = nst1; ntP = nntC;
+        pC = pB; aC = naB; mC = nmB; dC = ndB;
+        pB = nA;
     }
 }
 
@@ -307,7 +405,7 @@ void launch_region_voting_pass(float *disp, short *binmap, uint8_t *mask, const 
     const int tw = vote_tiles_w(g.W);
     k_vote<<<dim3(8192), dim3(64), vote_lds_bytes(g.D), s>>>(disp, binmap, mask, list, count, newval, arms,
                                                                   tile_stamp, g.W, g.dmin, g.D, tau_s, tau_h, cap, tw,
-                                                                  stamp0, pass);
+                                                                  tw * vote_tiles_h(g.H), stamp0, pass);
     k_apply<<<dim3(512), dim3(256), 0, s>>>(disp, binmap, mask, list, count, newval, out_list, out_count, tile_stamp,
                                             g.W, g.dmin, g.D, tw, stamp0 + (uint32_t)pass);
 }
