@@ -748,10 +748,14 @@ template <int VEC, bool FULLD, int MODE> struct FusedShape {
 template <int VEC, bool FULLD, int MODE>
 __global__ void __launch_bounds__(AGG_WAVES * 64)
 k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 *__restrict__ desc,
-            int W, int H, int Dp, int vertical, int cap, int R1, int R2, int dpad) {
-    // One workgroup = one whole line x one chunk of disparities. cap: the arm cap rounded up to an even number.
+            int W, int H, int Dp, int vertical, int cap, int R1, int R2, int dpad, int nwhole, int npieces, int piece_len) {
+    // One workgroup = one line x one chunk of disparities. cap: the arm cap rounded up to an even number.
     // Blocks start at multiples of B, so every pair of positions starts at an even position of the line and at
     // an even ring slot (R1, R2 are even): a pair never straddles the end of a ring.
+    // Work items (blockIdx.y): the first nwhole lines whole; every later line as npieces pieces of piece_len positions
+    // (a multiple of B), so that the workgroups left over after the last full round over the CUs are short ones
+    // (see launch_aggregate_fused_pair). A piece [org, end) runs the march from org - B*nlead: stage 1 recomputes
+    // the cap positions in front of it, stage 2 starts at org.
     typedef typename VecT<VEC>::T vec_t;
     typedef volatile vec_t __attribute__((address_space(3))) *lds_vec_ptr;
     constexpr int SLOT = 64 * VEC;
@@ -763,8 +767,14 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kc = blockIdx.x * SLOT;
-    const int line = blockIdx.y;
     const int LEN = vertical ? H : W;
+    int line = blockIdx.y, org = 0, end = LEN;
+    if (line >= nwhole) {
+        const int j = line - nwhole, li = j / npieces;
+        line = nwhole + li;
+        org = (j - li * npieces) * piece_len;
+        end = min(LEN, org + piece_len);
+    }
     const int mstride = vertical ? W * Dp : Dp;
     const size_t lbase = (vertical ? (size_t)line * Dp : (size_t)line * W * Dp) + (size_t)kc;
     bool fok[VEC];
@@ -781,7 +791,7 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
     // one workgroup per CU has to keep that much of HBM's latency covered by itself). Positions before the line
     // (the lead-in: stage 1 has to run cap + B ahead) and behind it have zero descriptors and are skipped.
     const int nlead = (2 * cap + B - 1) / B + 1;
-    int pa = cap + B * (1 - nlead);               // <= -cap
+    int pa = org + cap + B * (1 - nlead);         // <= org - cap
     // ring 1 (R1 = 2*cap + 3*B slots): slot 0 <-> position pa - cap of the first iteration;
     // ring 2 (R2 = 2*cap + 2*B slots): slot 0 <-> the first pa
     {
@@ -818,7 +828,7 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
     constexpr int NFILL = FILL_X4 ? 1 : 2 * VEC;   // fill instructions per wave and iteration
     const float *fill_p4 = src + lbase + (lane & 31) * 4 + (ptrdiff_t)fp * mstride;
     const ptrdiff_t second = (lane >> 5) ? (ptrdiff_t)mstride : (ptrdiff_t)0;
-    float *out_p = dst + lbase + lane * VEC + (ptrdiff_t)(2 * wave - B * nlead) * mstride;   // (stored to inside the line only)
+    float *out_p = dst + lbase + lane * VEC + (ptrdiff_t)(org + 2 * wave - B * nlead) * mstride;   // (stored to inside the piece only)
     // The workgroup's pair descriptors travel like the fills: by LDS-DMA, two iterations ahead of their use, into a
     // small staging area behind the rings (three 512-byte buffers used in turn: one being read, one landed, one in
     // flight). ONE instruction of one wave (wave 0, or the loader wave) moves
@@ -833,7 +843,7 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
     constexpr int DW = LOADER ? CW : 0;            // the wave that brings the descriptors
     const size_t drow = (size_t)line * (((LEN + 1) >> 1) + 2 * dpad) + dpad;
     const uint4 *d1p = desc + drow + (pa >> 1);                    // stage-1 pairs of the first iteration
-    const uint4 *d2p = desc + drow - (B * nlead) / 2;              // stage-2 pairs of the first iteration
+    const uint4 *d2p = desc + drow + (org - B * nlead) / 2;        // stage-2 pairs of the first iteration (org, B even)
     const uint4 *dsrc = (lane < 16 ? d1p : d2p) + (lane & 15);
     float *const stage = ring2 + (size_t)R2 * SLOT;                // three buffers of 128 dwords
     const uint32_t stage_off = (uint32_t)(uintptr_t)stage + (uint32_t)wave * 16u;
@@ -868,7 +878,7 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
             int sbl = 2;
             const float *lsrc = src + lbase + (lane & 31) * 4;
             const int hi = lane >> 5;
-            for (int o0 = -B * nlead; o0 < LEN; o0 += B) {
+            for (int o0 = org - B * nlead; o0 < end; o0 += B) {
                 desc_dma(2, sbl);
                 for (int w = 0; w < CW; w++) {
                     const int p = fl + 2 * w;
@@ -901,7 +911,7 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
 #ifdef AGG_STAMP
     unsigned long long st[8] = {}, tprev = __builtin_readcyclecounter();
 #endif
-    for (int o0 = -B * nlead; o0 < LEN; o0 += B) {
+    for (int o0 = org - B * nlead; o0 < end; o0 += B) {
         // (a) the descriptors of the iteration after the next into the staging buffer that is free, then the fill.
         //     (Issuing the fills of half the waves between the stages instead, so that their queueing for the CU's
         //     DMA path overlaps the other half's sums, moved time between the phases of an iteration and left its
@@ -942,7 +952,7 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
         // (c) stage 2: outputs o, o + 1 from ring 2 (written before the previous barrier)
         int nstore = 0;
         vec_t out0 = {}, out1 = {};
-        if (d2c) {
+        if (d2c && o0 >= org) {                   // (in front of a piece the positions are real, but they are another piece's)
             desc_windows<VEC>(out0, out1, ro2, R2, q2, d2c);
             nstore = (d2c >> 31) ? 2 : 1;
         }
@@ -1164,8 +1174,29 @@ void launch_aggregate_fused_pair(const float *src, float *dst, const uint4 *desc
     const int B = mode == 1 ? FusedShape<2, true, 1>::B : PAIR_B;
     const int R1 = 2 * cap + 3 * B, R2 = 2 * cap + 2 * B;
     const size_t lds = (size_t)(R1 + R2) * SLOT * sizeof(float) + 3 * 512;   // + the descriptor staging buffers
-    dim3 grid(chunks, lines), block(AGG_WAVES * 64);
-#define ADC_FUSED_GO(V_, F_, M_) k_agg_fused<V_, F_, M_><<<grid, block, lds, s>>>(src, dst, desc, g.W, g.H, g.Dp, vertical, cap, R1, R2, pair_desc_pad(max_arm))
+    // One workgroup per CU at a time: chunks * lines workgroups run as so many rounds over the CUs, and when the last
+    // round is far from full (1080 rows x 2 chunks on 256 CUs: 8.44 rounds) most of the chip idles through it. The
+    // lines of that last round are then cut into pieces, as many as still fit one round, so that it is a short one.
+    const int LEN = vertical ? g.H : g.W;
+    const int slots = g.simds / 4;
+    int nwhole = lines, npieces = 1, piece_len = LEN;
+    {
+        const long long items = (long long)chunks * lines;
+        const int rem = (int)(items % slots);
+        const int k = rem ? slots / rem : 1;                     // pieces per line that keep the last round a single one
+        const int rem_lines = (rem + chunks - 1) / chunks;
+        const int plen = ((LEN + k - 1) / k + B - 1) / B * B;
+        if (g.tune.agg_split >= 2) {                             // test hook: every line in that many pieces
+            const int kk = g.tune.agg_split, pl = ((LEN + kk - 1) / kk + B - 1) / B * B;
+            if ((long long)pl * (kk - 1) < LEN) { nwhole = 0; npieces = kk; piece_len = pl; }
+        } else if (g.tune.agg_split && items > slots && k >= 2 && plen >= 4 * B && (long long)plen * (k - 1) < LEN) {
+            nwhole = lines - rem_lines;
+            npieces = k;
+            piece_len = plen;
+        }
+    }
+    dim3 grid(chunks, nwhole + (lines - nwhole) * npieces), block(AGG_WAVES * 64);
+#define ADC_FUSED_GO(V_, F_, M_) k_agg_fused<V_, F_, M_><<<grid, block, lds, s>>>(src, dst, desc, g.W, g.H, g.Dp, vertical, cap, R1, R2, pair_desc_pad(max_arm), nwhole, npieces, piece_len)
     if (vec == 2) {
         if (!fulld) ADC_FUSED_GO(2, false, 0);
         else if (mode == 1) ADC_FUSED_GO(2, true, 1);

@@ -347,6 +347,7 @@ Tuning tuning_from_env() {
     };
     get("ADC_AGG_VARIANT", t.agg_variant); get("ADC_AGG_FUSE", t.agg_fuse); get("ADC_AGG_PAIR", t.agg_pair);
     get("ADC_COST_FUSE", t.cost_fuse); get("ADC_AGG_DEPTH", t.agg_depth); get("ADC_AGG_MODE", t.agg_mode);
+    get("ADC_AGG_SPLIT", t.agg_split);
     get("ADC_WTA_FUSED", t.wta_fused); get("ADC_WTA_SCALAR", t.wta_scalar); get("ADC_INTERP_DOUBLE", t.interp_double);
     get("ADC_SCAN_SPLIT", t.scan_split); get("ADC_SCAN_HYBRID", t.scan_hybrid); get("ADC_HYB_MAIN", t.hyb_main);
     get("ADC_HYB_LEAN", t.hyb_lean); get("ADC_SCAN_LEAN", t.scan_lean);

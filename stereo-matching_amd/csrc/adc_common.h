@@ -21,6 +21,7 @@ struct Tuning {
     int cost_fuse = 1;      // ADC_COST_FUSE     0: the initial costs as a kernel of their own
     int agg_depth = 6;      // ADC_AGG_DEPTH     fill look-ahead of the ring kernel
     int agg_mode = 1;       // ADC_AGG_MODE      0 / 1: how the fused aggregation launch fills its first ring (see k_agg_fused)
+    int agg_split = 1;      // ADC_AGG_SPLIT     0: never cut the lines of a fused aggregation launch's last round over the CUs into pieces; n >= 2: every line in n pieces
     int wta_fused = -1;     // ADC_WTA_FUSED     0 / 1: left WTA as its own kernel / inside the last scanline pass
     int wta_scalar = 0;     // ADC_WTA_SCALAR    1: right WTA without 16-byte loads
     int interp_double = 0;  // ADC_INTERP_DOUBLE 1: interpolation rays from the double tables

@@ -558,3 +558,15 @@ def test_fused_aggregation_fill_modes(pkg, orc, synth, monkeypatch, mode, W, H, 
     L, R, _ = synth.pair(190, max(W, 16), max(H, 16), dmax - dmin)
     L, R = np.ascontiguousarray(L[:H, :W]), np.ascontiguousarray(R[:H, :W])
     check_against_oracle(pkg, orc, L, R, min_disparity=dmin, max_disparity=dmax)
+
+
+@pytest.mark.parametrize("split", ["0", "2", "3", "5"])
+@pytest.mark.parametrize("W,H,dmin,dmax", [(300, 200, 0, 256), (131, 333, -2, 126), (257, 96, 0, 64)])
+def test_fused_aggregation_line_pieces(pkg, orc, synth, monkeypatch, split, W, H, dmin, dmax):
+    """The fused aggregation launch cuts the lines of its last, partly filled round over the CUs into pieces; a piece
+    recomputes the first stage of the arm span in front of it. ADC_AGG_SPLIT=n cuts EVERY line into n pieces (0: none):
+    the volumes and the map must not depend on where a line is cut."""
+    monkeypatch.setenv("ADC_DEBUG_ENV", "1")
+    monkeypatch.setenv("ADC_AGG_SPLIT", split)
+    L, R, _ = synth.pair(191, W, H, dmax - dmin)
+    check_against_oracle(pkg, orc, L, R, min_disparity=dmin, max_disparity=dmax)

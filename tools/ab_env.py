@@ -19,4 +19,6 @@ for case in cases + cases:
         print(case, "FAILED", p.stderr[-800:])
         sys.exit(1)
     j = json.loads(p.stdout.strip().splitlines()[-1])
-    print("%-28s ms/frame %.3f  %s" % (case, j["ms_per_frame"], j["stage_ms"]), flush=True)
+    k = j["kernel_ms"]
+    print("%-28s ms/frame %.3f  aggr0/1/3/5/7 %.3f %.3f %.3f %.3f %.3f  %s"
+          % (case, j["ms_per_frame"], k["aggr0"], k["aggr1"], k["aggr3"], k["aggr5"], k["aggr7"], j["stage_ms"]), flush=True)
