@@ -570,3 +570,15 @@ def test_fused_aggregation_line_pieces(pkg, orc, synth, monkeypatch, split, W, H
     monkeypatch.setenv("ADC_AGG_SPLIT", split)
     L, R, _ = synth.pair(191, W, H, dmax - dmin)
     check_against_oracle(pkg, orc, L, R, min_disparity=dmin, max_disparity=dmax)
+
+
+@pytest.mark.parametrize("L1,W,H", [(70, 320, 200), (130, 300, 280), (255, 560, 300)])
+def test_region_voting_long_arms(pkg, orc, synth, L1, W, H):
+    """Arm caps far beyond the default 34 with thresholds that let the arms grow: region rows longer than a wave
+    instruction's share of lanes, regions taller than 64 rows (several chunks of row arms per pixel) and more tiles
+    under a region's bounding box than the two stamp loads per lane cover. Every tap against the oracle."""
+    L, R, _ = synth.pair(300 + L1, W, H, 48)
+    got = check_against_oracle(pkg, orc, L, R, max_disparity=48, cross_L1=L1, cross_L2=L1 // 2, cross_t1=60, cross_t2=40)
+    a = got["arms"].astype(int).reshape(-1, 4)
+    assert a.max() > min(L1, 254) * 0.9 and (a[:, 2] + a[:, 3] + 1).max() > 64      # long arms, tall regions did occur
+    assert got["mask_occ"].sum() + got["mask_mis"].sum() > 100                       # and there was something to vote on
