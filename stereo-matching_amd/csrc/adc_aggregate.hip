@@ -314,13 +314,20 @@ struct CostSrc {
     const float *lut_ad1, *lut_cen;   // t_ad[766], e_cen[65]
     int dmin, D;
 };
+// (defined with the fused kernel below) the sums of the two windows of a pair described by a pair descriptor
+template <int VEC>
+__device__ __forceinline__ void desc_windows(typename VecT<VEC>::T &acc0, typename VecT<VEC>::T &acc1, uint32_t base, int R,
+                                             int q, uint32_t d);
+// DESC: the window geometry of a wave's pair comes from the line's pair descriptors (see k_pair_desc below: worked out
+// once per frame, with the support counts as floats) instead of from the arms and counts of the two pixels -- less
+// than half the scalar instructions and branches per pair. Horizontal passes of frames that build the descriptors.
 // FULLD: Dp is a multiple of the chunk (64*VEC disparities), so every lane of every chunk is live and the
 // fills / stores need no lane predicate (each predicate costs an execution-mask save, a branch and a restore).
-template <int VEC, bool DIV, bool COST, bool FULLD>
+template <int VEC, bool DIV, bool COST, bool FULLD, bool DESC>
 __global__ void __launch_bounds__(AGG_WAVES * 64)
 k_agg_pair(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ arms,
            const uint32_t *__restrict__ cnt, int W, int H, int Dp, int vertical, int seglen, int cap, int R,
-           CostSrc cs) {
+           CostSrc cs, const uint4 *__restrict__ desc, int dpad) {
     typedef typename VecT<VEC>::T vec_t;
     constexpr int SLOT = 64 * VEC;
     constexpr int B = PAIR_B;
@@ -414,13 +421,20 @@ k_agg_pair(const float *__restrict__ src, float *__restrict__ dst, const uint32_
     const uint32_t *arm_p = arms + abase + (size_t)o * astride;
     const uint32_t *cnt_p = DIV ? cnt + abase + (size_t)o * astride : nullptr;
 
-    // arms / support counts are fetched (scalar loads) one iteration ahead of their use
+    // arms / support counts -- or the pair's descriptor -- are fetched (scalar loads) one iteration ahead of their use
     uint32_t a_cur[2] = {0u, 0u}, c_cur[2] = {1u, 1u};
+    const uint4 *dsc_p = DESC ? desc + (size_t)line * (size_t)(((LEN + 1) >> 1) + 2 * dpad) + dpad + (o >> 1) : nullptr;
+    uint4 d_cur = make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t ro = (uint32_t)(uintptr_t)rl;   // this lane's floats of slot 0 as an LDS byte offset
+    if (DESC) {
+        if (o < s1) d_cur = dsc_p[0];
+    } else {
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        if (o + j < s1) {
-            a_cur[j] = arm_p[j * astride];
-            if (DIV) c_cur[j] = cnt_p[j * astride];
+        for (int j = 0; j < 2; j++) {
+            if (o + j < s1) {
+                a_cur[j] = arm_p[j * astride];
+                if (DIV) c_cur[j] = cnt_p[j * astride];
+            }
         }
     }
 
@@ -450,16 +464,34 @@ k_agg_pair(const float *__restrict__ src, float *__restrict__ dst, const uint32_
         }
         __builtin_amdgcn_s_setprio(0);
         uint32_t a_nxt[2] = {0u, 0u}, c_nxt[2] = {1u, 1u};
+        uint4 d_nxt = make_uint4(0u, 0u, 0u, 0u);
+        if (DESC) {
+            if (o + B < s1) d_nxt = dsc_p[B / 2];
+        } else {
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            if (o + B + j < s1) {
-                a_nxt[j] = arm_p[blk_a + j * astride];
-                if (DIV) c_nxt[j] = cnt_p[blk_a + j * astride];
+            for (int j = 0; j < 2; j++) {
+                if (o + B + j < s1) {
+                    a_nxt[j] = arm_p[blk_a + j * astride];
+                    if (DIV) c_nxt[j] = cnt_p[blk_a + j * astride];
+                }
             }
         }
         // (b) this wave's two outputs. Windows in virtual ring slots (slot of position o is qo):
         //     chain 0 = [qo - neg0, qo + pos0], chain 1 = [qo + 1 - neg1, qo + 1 + pos1]
-        if (o < s1) {
+        if (DESC) {
+            if (d_cur.x) {               // (zero: no position here -- behind the end of the segment or of the line)
+                vec_t acc0, acc1;
+                desc_windows<VEC>(acc0, acc1, ro, R, qo, d_cur.x);
+                if (DIV) {
+                    acc0 = div_by_count<VEC>(acc0, __uint_as_float(d_cur.y));
+                    acc1 = div_by_count<VEC>(acc1, __uint_as_float(d_cur.z));
+                }
+                if (kok) {
+                    *reinterpret_cast<vec_t *>(out_p) = acc0;
+                    if (d_cur.x >> 31) *reinterpret_cast<vec_t *>(out_p + mstride) = acc1;
+                }
+            }
+        } else if (o < s1) {
             const bool two = o + 1 < s1;
             const int b0 = qo - (int)((a_cur[0] >> sh_neg) & 0xff), e0 = qo + (int)((a_cur[0] >> sh_pos) & 0xff);
             // a missing second position gets an empty window placed after the first one's
@@ -491,6 +523,8 @@ k_agg_pair(const float *__restrict__ src, float *__restrict__ dst, const uint32_
         }
 #pragma unroll
         for (int j = 0; j < 2; j++) { a_cur[j] = a_nxt[j]; c_cur[j] = c_nxt[j]; }
+        d_cur = d_nxt;
+        if (DESC) dsc_p += B / 2;
         // (c) the next block's fills must have landed before anyone reads them. Once a fill has been
         //     skipped (end of the line / segment) no further fill follows: drain once, then stop waiting.
         if (!COST && fills_live) {            // (COST: the ring is written by ds_write, ordered by the wait below)
@@ -1078,7 +1112,7 @@ static void launch_ring(const float *src, float *dst, const uint32_t *arms, cons
 
 template <int VEC>
 static void launch_pair(const float *src, float *dst, const uint32_t *arms, const uint32_t *cnt, const Geom &g,
-                        int vertical, int max_arm, const CostSrc *cost, hipStream_t s) {
+                        int vertical, int max_arm, const CostSrc *cost, const uint4 *desc, hipStream_t s) {
     const int SLOT = 64 * VEC;
     const int chunks = (g.Dp + SLOT - 1) / SLOT;
     const int lines = vertical ? g.W : g.H;
@@ -1106,15 +1140,23 @@ static void launch_pair(const float *src, float *dst, const uint32_t *arms, cons
     const bool fulld = g.Dp % SLOT == 0;
 #endif
     const CostSrc none = {};
-#define ADC_PAIR_GO(D_, C_, CS_)                                                                                              \
-    do {                                                                                                                      \
-        if (fulld) k_agg_pair<VEC, D_, C_, true><<<grid, block, lds, s>>>(src, dst, arms, cnt, g.W, g.H, g.Dp, vertical, seglen, max_arm, R, CS_); \
-        else k_agg_pair<VEC, D_, C_, false><<<grid, block, lds, s>>>(src, dst, arms, cnt, g.W, g.H, g.Dp, vertical, seglen, max_arm, R, CS_);      \
+    const int dpad = pair_desc_pad(max_arm);
+#define ADC_PAIR_ARGS(CS_) src, dst, arms, cnt, g.W, g.H, g.Dp, vertical, seglen, max_arm, R, CS_, desc, dpad
+#define ADC_PAIR_GO(D_, C_, CS_)                                                                                  \
+    do {                                                                                                          \
+        if (desc) {                                                                                               \
+            if (fulld) k_agg_pair<VEC, D_, C_, true, true><<<grid, block, lds, s>>>(ADC_PAIR_ARGS(CS_));          \
+            else k_agg_pair<VEC, D_, C_, false, true><<<grid, block, lds, s>>>(ADC_PAIR_ARGS(CS_));               \
+        } else {                                                                                                  \
+            if (fulld) k_agg_pair<VEC, D_, C_, true, false><<<grid, block, lds, s>>>(ADC_PAIR_ARGS(CS_));         \
+            else k_agg_pair<VEC, D_, C_, false, false><<<grid, block, lds, s>>>(ADC_PAIR_ARGS(CS_));              \
+        }                                                                                                         \
     } while (0)
     if (cost) ADC_PAIR_GO(false, true, *cost);
     else if (cnt) ADC_PAIR_GO(true, false, none);
     else ADC_PAIR_GO(false, false, none);
 #undef ADC_PAIR_GO
+#undef ADC_PAIR_ARGS
 }
 
 // The dynamic-LDS opt-in of every instantiation a launcher above can pick (the ring kernels use up to 64 KB,
@@ -1131,7 +1173,9 @@ static hipError_t setup_vec() {
     set(reinterpret_cast<const void *>(&k_agg_ring<VEC, false, D_>), 64 * 1024)
     ADC_RING_ATTR(2); ADC_RING_ATTR(4); ADC_RING_ATTR(6);
 #undef ADC_RING_ATTR
-#define ADC_PAIR_ATTR(D_, C_, F_) set(reinterpret_cast<const void *>(&k_agg_pair<VEC, D_, C_, F_>), 80 * 1024)
+#define ADC_PAIR_ATTR(D_, C_, F_)                                                               \
+    set(reinterpret_cast<const void *>(&k_agg_pair<VEC, D_, C_, F_, false>), 80 * 1024);        \
+    set(reinterpret_cast<const void *>(&k_agg_pair<VEC, D_, C_, F_, true>), 80 * 1024)
     ADC_PAIR_ATTR(true, false, true); ADC_PAIR_ATTR(false, false, true); ADC_PAIR_ATTR(false, true, true);
     ADC_PAIR_ATTR(true, false, false); ADC_PAIR_ATTR(false, false, false); ADC_PAIR_ATTR(false, true, false);
 #undef ADC_PAIR_ATTR
@@ -1225,15 +1269,19 @@ bool aggregate_cost_fusion_supported(const Geom &g, int max_arm) {
     return env && pair_kernel_ok(g, max_arm) && room >= 128;
 }
 void launch_aggregate_first_pass_with_cost(const Planes &p, const float *lut_ad1, const float *lut_cen, float *dst,
-                                           const Geom &g, int max_arm, hipStream_t s) {
+                                           const Geom &g, int max_arm, const uint4 *desc_h, hipStream_t s) {
     const CostSrc cs = {p.pix_l, p.pix_r, p.cen_l, p.cen_r, lut_ad1, lut_cen, g.dmin, g.D};
     const int vec = (g.Dp >= 128 && g.Dp % 2 == 0) ? 2 : 1;
-    if (vec == 2) launch_pair<2>(nullptr, dst, p.arms, nullptr, g, 0, max_arm, &cs, s);
-    else launch_pair<1>(nullptr, dst, p.arms, nullptr, g, 0, max_arm, &cs, s);
+    if (!g.tune.agg_desc) desc_h = nullptr;
+    if (vec == 2) launch_pair<2>(nullptr, dst, p.arms, nullptr, g, 0, max_arm, &cs, desc_h, s);
+    else launch_pair<1>(nullptr, dst, p.arms, nullptr, g, 0, max_arm, &cs, desc_h, s);
 }
 
+// desc: the pair descriptors of the pass's axis whose counts are the ones this pass divides by (or does not divide), or
+// null: then the windows come from the arms (and cnt)
 void launch_aggregate_pass(const float *src, float *dst, const uint32_t *arms, const uint32_t *cnt,
-                           const Geom &g, int vertical, int max_arm, int variant, hipStream_t s) {
+                           const Geom &g, int vertical, int max_arm, int variant, const uint4 *desc, hipStream_t s) {
+    if (!g.tune.agg_desc) desc = nullptr;
     // deepest fill look-ahead (6, 4 or 2 iterations) whose ring still fits 64 KB of LDS
     const int depth_env = g.tune.agg_depth;
     const bool strides_ok = (long long)g.W * g.Dp * (AGG_WAVES + 1) < (1ll << 31);
@@ -1247,8 +1295,8 @@ void launch_aggregate_pass(const float *src, float *dst, const uint32_t *arms, c
     }
     // two positions per wave when its ring (2*cap + 64 slots) leaves room for two workgroups per CU
     if (variant == 0 && pair_kernel_ok(g, max_arm)) {
-        if (vec == 2) launch_pair<2>(src, dst, arms, cnt, g, vertical, max_arm, nullptr, s);
-        else launch_pair<1>(src, dst, arms, cnt, g, vertical, max_arm, nullptr, s);
+        if (vec == 2) launch_pair<2>(src, dst, arms, cnt, g, vertical, max_arm, nullptr, desc, s);
+        else launch_pair<1>(src, dst, arms, cnt, g, vertical, max_arm, nullptr, desc, s);
     } else if (variant == 0 && strides_ok && depth) {
 #define ADC_RING(V, D) launch_ring<V, D>(src, dst, arms, cnt, g, vertical, max_arm, R, s)
         if (vec == 2) { if (depth == 6) ADC_RING(2, 6); else if (depth == 4) ADC_RING(2, 4); else ADC_RING(2, 2); }

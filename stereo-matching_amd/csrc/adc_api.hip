@@ -347,7 +347,7 @@ Tuning tuning_from_env() {
     };
     get("ADC_AGG_VARIANT", t.agg_variant); get("ADC_AGG_FUSE", t.agg_fuse); get("ADC_AGG_PAIR", t.agg_pair);
     get("ADC_COST_FUSE", t.cost_fuse); get("ADC_AGG_DEPTH", t.agg_depth); get("ADC_AGG_MODE", t.agg_mode);
-    get("ADC_AGG_SPLIT", t.agg_split);
+    get("ADC_AGG_SPLIT", t.agg_split); get("ADC_AGG_DESC", t.agg_desc);
     get("ADC_WTA_FUSED", t.wta_fused); get("ADC_WTA_SCALAR", t.wta_scalar); get("ADC_INTERP_DOUBLE", t.interp_double);
     get("ADC_SCAN_SPLIT", t.scan_split); get("ADC_SCAN_HYBRID", t.scan_hybrid); get("ADC_HYB_MAIN", t.hyb_main);
     get("ADC_HYB_LEAN", t.hyb_lean); get("ADC_SCAN_LEAN", t.scan_lean);
@@ -409,10 +409,10 @@ int enqueue_match(adc_handle *h, const uint8_t *d_l, const uint8_t *d_r, float *
         KMARK(ADC_KERNEL_AGGR0);
         if (fuse_cost) {
             cur_v = h->vol_b; oth_v = h->vol_a;    // nothing lives in either volume yet
-            launch_aggregate_first_pass_with_cost(pl, h->lut_ad1, h->lut_cen, cur_v, g, cap, s);
+            launch_aggregate_first_pass_with_cost(pl, h->lut_ad1, h->lut_cen, cur_v, g, cap, pl.pair_h, s);
         } else {
             cur_v = h->vol_a; oth_v = h->vol_b;
-            launch_aggregate_pass(h->vol_b, cur_v, pl.arms, nullptr, g, 0, cap, 0, s);
+            launch_aggregate_pass(h->vol_b, cur_v, pl.arms, nullptr, g, 0, cap, 0, pl.pair_h, s);
         }
         for (int k = 0; k < 3; k++) {
             const int vertical = (k % 2) == 0;
@@ -422,19 +422,19 @@ int enqueue_match(adc_handle *h, const uint8_t *d_l, const uint8_t *d_r, float *
             std::swap(cur_v, oth_v);
         }
         KMARK(ADC_KERNEL_AGGR0 + 7);
-        launch_aggregate_pass(cur_v, oth_v, pl.arms, pl.cnt_v32, g, 0, cap, 0, s);
+        launch_aggregate_pass(cur_v, oth_v, pl.arms, pl.cnt_v32, g, 0, cap, 0, pl.pair_h, s);
         std::swap(cur_v, oth_v);
     } else {
         for (int it = 0; it < 4; it++) {
             const bool hfirst = (it % 2) == 0;
             KMARK(ADC_KERNEL_AGGR0 + 2 * it);
             if (it == 0 && fuse_cost)
-                launch_aggregate_first_pass_with_cost(pl, h->lut_ad1, h->lut_cen, h->vol_a, g, cap, s);
+                launch_aggregate_first_pass_with_cost(pl, h->lut_ad1, h->lut_cen, h->vol_a, g, cap, nullptr, s);
             else
-                launch_aggregate_pass(h->vol_b, h->vol_a, pl.arms, nullptr, g, hfirst ? 0 : 1, cap, h->tune.agg_variant, s);
+                launch_aggregate_pass(h->vol_b, h->vol_a, pl.arms, nullptr, g, hfirst ? 0 : 1, cap, h->tune.agg_variant, nullptr, s);
             KMARK(ADC_KERNEL_AGGR0 + 2 * it + 1);
             launch_aggregate_pass(h->vol_a, h->vol_b, pl.arms, hfirst ? pl.cnt_h32 : pl.cnt_v32, g, hfirst ? 1 : 0, cap,
-                                  h->tune.agg_variant, s);
+                                  h->tune.agg_variant, nullptr, s);
         }
         cur_v = h->vol_b; oth_v = h->vol_a;
     }

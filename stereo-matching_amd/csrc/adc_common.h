@@ -21,6 +21,7 @@ struct Tuning {
     int cost_fuse = 1;      // ADC_COST_FUSE     0: the initial costs as a kernel of their own
     int agg_depth = 6;      // ADC_AGG_DEPTH     fill look-ahead of the ring kernel
     int agg_mode = 1;       // ADC_AGG_MODE      0 / 1: how the fused aggregation launch fills its first ring (see k_agg_fused)
+    int agg_desc = 1;       // ADC_AGG_DESC      0: the single-pass pair kernel works its windows out from the arms even where pair descriptors exist
     int agg_split = 1;      // ADC_AGG_SPLIT     0: never cut the lines of a fused aggregation launch's last round over the CUs into pieces; n >= 2: every line in n pieces
     int wta_fused = -1;     // ADC_WTA_FUSED     0 / 1: left WTA as its own kernel / inside the last scanline pass
     int wta_scalar = 0;     // ADC_WTA_SCALAR    1: right WTA without 16-byte loads
@@ -83,13 +84,13 @@ hipError_t aggregate_setup_device();
 // vertical = 0: span along x (left/right arms); 1: along y (top/bottom arms). cnt == nullptr: no division.
 // variant: 0 = ring kernel (LDS), 1 = direct-global fallback.
 void launch_aggregate_pass(const float *src, float *dst, const uint32_t *arms, const uint32_t *cnt,
-                           const Geom &g, int vertical, int max_arm, int variant, hipStream_t s);
+                           const Geom &g, int vertical, int max_arm, int variant, const uint4 *desc, hipStream_t s);
 // The first pass (horizontal, no division) with the initial cost volume computed inside the kernel
 // instead of being read: only when aggregate_cost_fusion_supported().
 bool aggregate_cost_fusion_supported(const Geom &g, int max_arm);
 // lut_ad1[s] = (1.0f - e_ad[s]) + 1.0f, evaluated in fp32 on the host
 void launch_aggregate_first_pass_with_cost(const Planes &p, const float *lut_ad1, const float *lut_cen, float *dst,
-                                           const Geom &g, int max_arm, hipStream_t s);
+                                           const Geom &g, int max_arm, const uint4 *desc_h, hipStream_t s);
 
 // A dividing pass and the plain pass that follows it along the same axis (passes 1+2, 3+4, 5+6 of the eight)
 // as one launch, the intermediate volume staying in LDS: only when aggregate_pair_fusion_supported().
