@@ -1053,6 +1053,315 @@ extern "C" int adc_debug_agg_stamps(unsigned long long *out) {
 }
 #endif
 
+// ---- the same-axis pair of passes on the matrix pipe ---------------------------------------------------------
+// v_mfma_f32_4x4x1_16b_f32 computes, for sixteen independent 4x4 blocks, D[i][j] = C[i][j] + a[i] * b[j]: with K = 1
+// every element of D receives exactly ONE product and ONE rounding per instruction. With b[j] in {0.0, 1.0} that is
+// "add the term a[i] to the window sum j if the term belongs to window j" -- the masked addition of the vector kernels
+// above (fma(v, 1, acc) rounds as v + acc does, fma(v, 0, acc) is acc), 256 of them per instruction:
+//     block k, column j  <->  disparity 4k + j of a 64-disparity term       (B: lane 4k + j holds the term's value)
+//     row i              <->  one of FOUR neighbouring positions of the line  (A: lane 4k + i holds window i's factor)
+//     D                  <->  lane 4k + j, register i: the running sum of window i at disparity 4k + j
+// so a lane keeps "its" disparity throughout (ring reads, results, stores are all lane <-> disparity) and the four
+// windows are the four accumulator registers.
+// Each sum still receives its own terms in ascending position order from 0.0f, one IEEE addition per term (checked
+// against sequential fp32 sums on a million accumulators by tools/microbench/mfma_add_probe.hip): identical bits.
+// What the matrix pipe offers: a term is read from the ring once for four windows, the window geometry is decoded once
+// per four outputs and no per-window branching is left (a term outside a window costs a factor, not a branch); alone, a
+// SIMD retires ~27 such additions per clock this way (tools/microbench/mfma_add_probe.hip) against the ~9 the vector
+// kernel sustains. Inside this kernel it does not get there: a 4x4x1 instruction holds the SIMD's vector issue for its
+// whole 8 cycles, the factors of head and tail terms are vector instructions of their own, and with one workgroup per CU
+// the waves pass through their matrix phases together and leave the pipe idle through the rest of an iteration
+// (divide, ring and memory writes, barrier): 1.72 ms per launch at 1920x1080x256 against 1.39 ms of k_agg_fused. It is
+// kept as Tuning::agg_mode = 2, bit-identical and tested, not as the default.
+//
+// Quad descriptor (8 dwords) of the positions p .. p+3 of a line, p a multiple of 4. The union of the four windows is
+// one run of ring slots; "head" = its terms in front of the last window's first term, "core" = the terms all four
+// windows hold, "tail" = the rest (all of the run is head when there is no term common to all four):
+//   w0  bits 0..7 distance of the run's first term below p | 8..15 head terms | 16..23 core terms | 24..31 tail terms
+//   w1  bits 0..3: position p + j exists (a line's last quad may be short); 0 = no position here at all
+//   w2  byte j: first term of window j, counted from the run's first term (255 for a missing position)
+//   w3  byte j: last term of window j, likewise (255 for a missing position: a run has fewer than 255 terms)
+//   w4..w7  support count of p + j as float (1.0f for a missing position)
+// Rows are padded with quad_desc_pad() all-zero records in front and behind, like the pair descriptors.
+#ifndef QUAD_NQ
+#define QUAD_NQ 8                       // quads per iteration = computing waves (a wave owns a quad x all 128 disparities)
+#endif
+#ifndef QUAD_NL
+#define QUAD_NL 2                       // loader waves
+#endif
+#define QUAD_B (4 * QUAD_NQ)            // positions per iteration
+#define QUAD_WAVES (QUAD_NQ + QUAD_NL)
+int quad_cap(int max_arm) { return (max_arm + 3) & ~3; }
+int quad_desc_pad(int max_arm) { return (quad_cap(max_arm) + 3 * QUAD_B) / 4 + 8; }
+size_t quad_desc_count(int lines, int len, int max_arm) { return (size_t)lines * ((len + 3) / 4 + 2 * quad_desc_pad(max_arm)) * 2; }   // in uint4
+
+__global__ void __launch_bounds__(256)
+k_quad_desc(const uint32_t *__restrict__ arms, const uint32_t *__restrict__ cnt_for_h, const uint32_t *__restrict__ cnt_for_v,
+            uint4 *__restrict__ desc_h, uint4 *__restrict__ desc_v, int W, int H, int pad) {
+    const int vertical = blockIdx.z;
+    const int LEN = vertical ? H : W, lines = vertical ? W : H;
+    const int nquads = (LEN + 3) >> 2;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)lines * nquads) return;
+    int line, quad;
+    if (vertical) { line = (int)(gid % W); quad = (int)(gid / W); }
+    else { line = (int)(gid / nquads); quad = (int)(gid - (size_t)line * nquads); }
+    const int p = 4 * quad;
+    const uint32_t *cnt = vertical ? cnt_for_v : cnt_for_h;
+    const int sh_neg = vertical ? 16 : 0, sh_pos = vertical ? 24 : 8;
+    int b[4], e[4];
+    float c[4];
+    uint32_t valid = 0;
+    int umin = 1 << 20, umax = -(1 << 20), bmax = -(1 << 20), emin = 1 << 20;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        c[j] = 1.0f;
+        b[j] = 0; e[j] = -1;
+        if (p + j < LEN) {
+            const size_t i = vertical ? (size_t)(p + j) * W + line : (size_t)line * W + p + j;
+            const uint32_t a = arms[i];
+            b[j] = j - (int)((a >> sh_neg) & 0xff);
+            e[j] = j + (int)((a >> sh_pos) & 0xff);
+            c[j] = (float)cnt[i];
+            valid |= 1u << j;
+            umin = min(umin, b[j]); umax = max(umax, e[j]);
+            bmax = max(bmax, b[j]); emin = min(emin, e[j]);
+        }
+    }
+    int nh, nc, nt;
+    if (bmax <= emin) { nh = bmax - umin; nc = emin - bmax + 1; nt = umax - emin; }
+    else { nh = umax - umin + 1; nc = 0; nt = 0; }
+    uint32_t rb = 0, re = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const bool ok = (valid >> j) & 1u;
+        rb |= (uint32_t)(ok ? b[j] - umin : 255) << (8 * j);     // (a missing position: a window no term index reaches)
+        re |= (uint32_t)(ok ? e[j] - umin : 255) << (8 * j);
+    }
+    const uint32_t w0 = (uint32_t)(-umin) | (uint32_t)nh << 8 | (uint32_t)nc << 16 | (uint32_t)nt << 24;
+    uint4 *out = (vertical ? desc_v : desc_h) + ((size_t)line * (nquads + 2 * pad) + pad + quad) * 2;
+    out[0] = make_uint4(w0, valid, rb, re);
+    out[1] = make_uint4(__float_as_uint(c[0]), __float_as_uint(c[1]), __float_as_uint(c[2]), __float_as_uint(c[3]));
+}
+void launch_quad_descriptors(const uint32_t *arms, const uint32_t *cnt_for_h, const uint32_t *cnt_for_v, uint4 *desc_h,
+                             uint4 *desc_v, const Geom &g, int max_arm, hipStream_t s) {
+    const size_t n = std::max((size_t)g.H * ((g.W + 3) / 4), (size_t)g.W * ((g.H + 3) / 4));
+    k_quad_desc<<<dim3((unsigned)((n + 255) / 256), 1, 2), dim3(256), 0, s>>>(arms, cnt_for_h, cnt_for_v, desc_h, desc_v, g.W, g.H,
+                                                                              quad_desc_pad(max_arm));
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// A lane holds the disparities 2*lane and 2*lane + 1 of the workgroup's 128 (one ds_read_b64 per term, as in the vector
+// kernels): two independent accumulator sets, whose matrix instructions alternate -- a dependent chain of its own would
+// leave the pipe idle between its instructions.
+// G consecutive ring slots from LDS byte offset o (this lane's two floats of slot 0 included): the terms i0 .. i0+G-1 of
+// a quad's run added to its four window sums. MASKED: a term goes to window j (the lane's lane & 3) only if
+// rb <= i <= rb + span; otherwise (core terms) to all four.
+template <int G, bool MASKED>
+__device__ __forceinline__ void quad_group(f32x4 &a0, f32x4 &a1, uint32_t o, int i0, uint32_t rb, uint32_t span) {
+    f32x2 v[G];
+#pragma unroll
+    for (int u = 0; u < G; u++) v[u] = ring_read_o<f32x2>(o + u * 512u);
+#pragma unroll
+    for (int u = 0; u < G; u++) {
+        float f = 1.0f;
+        if (MASKED) f = ((uint32_t)(i0 + u) - rb <= span) ? 1.0f : 0.0f;
+        a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(f, v[u].x, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(f, v[u].y, a1, 0, 0, 0);
+    }
+}
+// n terms from byte offset o (no ring wrap inside), the first being term i0 of the run; [c0, c1) are the core terms
+__device__ __forceinline__ void quad_span(f32x4 &a0, f32x4 &a1, uint32_t o, int i0, int n, int c0, int c1, uint32_t rb, uint32_t span) {
+    for (; n >= 8; n -= 8, i0 += 8, o += 8 * 512u) {
+        if (i0 >= c0 && i0 + 8 <= c1) quad_group<8, false>(a0, a1, o, i0, rb, span);
+        else quad_group<8, true>(a0, a1, o, i0, rb, span);
+    }
+    if (n & 4) { quad_group<4, true>(a0, a1, o, i0, rb, span); i0 += 4; o += 4 * 512u; }
+    if (n & 2) { quad_group<2, true>(a0, a1, o, i0, rb, span); i0 += 2; o += 2 * 512u; }
+    if (n & 1) quad_group<1, true>(a0, a1, o, i0, rb, span);
+}
+// The four window sums of a quad from the ring at LDS byte offset `base` (this lane's floats of slot 0; R slots of
+// 512 bytes); q = slot of the quad's first position; w0: the descriptor's first word; rb / re: this lane's window.
+__device__ __forceinline__ void quad_windows(f32x4 &a0, f32x4 &a1, uint32_t base, int R, int q, uint32_t w0, uint32_t rb, uint32_t re) {
+    const int nh = (w0 >> 8) & 255, nc = (w0 >> 16) & 255, nt = w0 >> 24;
+    const int n = nh + nc + nt;
+    int u = q - (int)(w0 & 255u);
+    if (u < 0) u += R;
+    const uint32_t span = re - rb;          // (a missing position: rb = re = 255, never reached)
+    a0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    a1 = a0;
+    const int n1 = min(n, R - u);
+    quad_span(a0, a1, base + (uint32_t)u * 512u, 0, n1, nh, nh + nc, rb, span);
+    if (n > n1) quad_span(a0, a1, base, n1, n - n1, nh, nh + nc, rb, span);
+}
+
+__global__ void __launch_bounds__(QUAD_WAVES * 64)
+k_agg_fused_q(const float *__restrict__ src, float *__restrict__ dst, const uint4 *__restrict__ desc,
+              int W, int H, int Dp, int vertical, int cap, int R1, int R2, int dpad, int nwhole, int npieces, int piece_len) {
+    // One workgroup = one line (or piece of a line) x 128 disparities: NQ computing waves, one quad of positions each,
+    // and NL loader waves. cap: the arm cap rounded up to a multiple of 4; blocks start at multiples of B = 4 NQ and
+    // R1, R2 are multiples of 4: a quad's four ring slots never wrap.
+    constexpr int SLOT = 128, B = QUAD_B, NQ = QUAD_NQ, NL = QUAD_NL;
+    static_assert(NQ == 8, "the descriptor DMA below moves sixteen 16-byte chunks per stage");
+    extern __shared__ __align__(16) float ring[];   // ring 1 (src): R1 x SLOT, ring 2 (A): R2 x SLOT, descriptor staging
+    float *const ring2 = ring + (size_t)R1 * SLOT;
+    float *const stage = ring2 + (size_t)R2 * SLOT; // three buffers of 128 dwords
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kc = blockIdx.x * SLOT;
+    const int LEN = vertical ? H : W;
+    int line = blockIdx.y, org = 0, end = LEN;
+    if (line >= nwhole) {
+        const int j = line - nwhole, li = j / npieces;
+        line = nwhole + li;
+        org = (j - li * npieces) * piece_len;
+        end = min(LEN, org + piece_len);
+    }
+    const int mstride = vertical ? W * Dp : Dp;
+    const size_t lbase = (vertical ? (size_t)line * Dp : (size_t)line * W * Dp) + (size_t)kc;
+    const int nlead = (2 * cap + B - 1) / B + 1;
+    const int pa = org + cap + B * (1 - nlead);   // stage-1 positions of the first iteration start here (<= org - cap)
+    // prologue: ring-1 slot i <-> position pa - cap + i, i < 2*cap + 2*B
+    {
+        const float *fsrc = src + lbase + lane;
+        for (int i = wave; i < 2 * cap + 2 * B; i += QUAD_WAVES) {
+            const int x = pa - cap + i;
+            if (x >= 0 && x < LEN) {
+                ring_fill(fsrc + (size_t)x * mstride, ring + i * SLOT);
+                ring_fill_hi(fsrc + (size_t)x * mstride, ring + i * SLOT);
+            }
+        }
+    }
+    // descriptors: 8 quads x 32 bytes per stage and iteration, brought by ONE 16-byte-per-lane LDS-DMA of the first
+    // loader wave two iterations ahead (lanes 0..15: the stage-1 records, lanes 16..31: the stage-2 records)
+    const size_t drow = ((size_t)line * (size_t)(((LEN + 3) >> 2) + 2 * dpad) + dpad) * 2;
+    const uint4 *d1p = desc + drow + (ptrdiff_t)(pa / 4) * 2;                      // (pa is a multiple of 4, maybe negative)
+    const uint4 *d2p = desc + drow + (ptrdiff_t)((org - B * nlead) / 4) * 2;
+    const uint4 *dsrc = (lane < 16 ? d1p : d2p) + (lane & 15);
+    auto desc_dma = [&](int it_ahead, int buf) {
+        if (wave == NQ && lane < 32)
+            __builtin_amdgcn_global_load_lds(dsrc + (ptrdiff_t)it_ahead * (2 * NQ),
+                                             (__attribute__((address_space(3))) void *)(stage + buf * 128), 16, 0, 0);
+    };
+    desc_dma(0, 0);
+    desc_dma(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    if (wave >= NQ) {
+        // A loader wave: per iteration (the first one: the descriptor DMA and) its share of the fills of the block two
+        // iterations ahead, one 16-byte-per-lane DMA per pair of positions (pairs li, li + NL, ...); it waits for the
+        // PREVIOUS iteration's, then joins the barrier that publishes them.
+        const int li = wave - NQ;
+        constexpr int MINE = (2 * NQ + NL - 1) / NL;     // pairs per loader wave and iteration (16 pairs in all)
+        static_assert((2 * NQ) % NL == 0, "every loader wave issues the same number of fills");
+        int fl = pa + 2 * B + cap;             // > 0
+        int ql = 2 * cap + 2 * B;              // < R1
+        int sbl = 2;
+        const float *lsrc = src + lbase + (lane & 31) * 4;
+        const int hi = lane >> 5;
+        for (int o0 = org - B * nlead; o0 < end; o0 += B) {
+            desc_dma(2, sbl);
+#pragma unroll
+            for (int k = 0; k < MINE; k++) {
+                const int w = li + k * NL;
+                const int p = fl + 2 * w;
+                if (p < LEN) {
+                    int q = ql + 2 * w;
+                    if (q >= R1) q -= R1;
+                    const int pl = min(p + hi, LEN - 1);
+                    ring_fill_x4(lsrc + (ptrdiff_t)pl * mstride, ring + q * SLOT);
+                }
+            }
+            if (fl + B <= LEN) {
+                if (li == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 + MINE) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MINE) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            fl += B;
+            ql += B; if (ql >= R1) ql -= R1;
+            sbl = sbl == 2 ? 0 : sbl + 1;
+            dsrc += 2 * NQ;
+        }
+        return;
+    }
+
+    const int quad = wave;
+    const int col = lane & 3;                              // the window this lane's factor belongs to
+    int q1 = cap + 4 * quad;                              // ring-1 slot of the quad's first stage-1 position
+    int qw = 4 * quad;                                    // ring-2 slot of it
+    int q2 = R2 - ((cap + B) % R2) + 4 * quad;            // ring-2 slot of the quad's first stage-2 position
+    if (q2 >= R2) q2 -= R2;
+    const uint32_t ro1 = (uint32_t)(uintptr_t)ring + (uint32_t)lane * 8u;
+    const uint32_t ro2 = (uint32_t)(uintptr_t)ring2 + (uint32_t)lane * 8u;
+    // register i of an accumulator = window i (position 4*quad + i of the block); the two accumulators = this lane's two disparities
+    float *out_p = dst + lbase + 2 * lane + (ptrdiff_t)(org + 4 * quad - B * nlead) * mstride;
+    const ptrdiff_t blk_m = (ptrdiff_t)B * mstride;
+    const uint32_t stage_off = (uint32_t)(uintptr_t)stage + (uint32_t)quad * 32u;
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x4q __attribute__((ext_vector_type(4)));
+    auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    int sb = 0;
+#ifdef AGG_STAMP
+    unsigned long long st[8] = {}, tprev = __builtin_readcyclecounter();
+#endif
+    for (int o0 = org - B * nlead; o0 < end; o0 += B) {
+        // this iteration's records (published by the previous barrier): uniform words, then this lane's window bounds
+        const uint32_t rec1 = stage_off + (uint32_t)sb * 512u, rec2 = rec1 + 256u;
+        const u32x2 h1 = ring_read_o<u32x2>(rec1), h2 = ring_read_o<u32x2>(rec2);
+        const uint32_t rb1 = ring_read_o<uint8_t>(rec1 + 8u + (uint32_t)col), re1 = ring_read_o<uint8_t>(rec1 + 12u + (uint32_t)col);
+        const uint32_t rb2 = ring_read_o<uint8_t>(rec2 + 8u + (uint32_t)col), re2 = ring_read_o<uint8_t>(rec2 + 12u + (uint32_t)col);
+        const u32x4q cv = ring_read_o<u32x4q>(rec1 + 16u);          // the four support counts of the stage-1 quad
+        const uint32_t w0a = uni(h1.x), va = uni(h1.y), w0b = uni(h2.x), vb = uni(h2.y);
+        STAMP(0)
+        // stage 1: A of the quad's positions into ring 2
+        if (va) {
+            f32x4 a0, a1;
+            quad_windows(a0, a1, ro1, R1, q1, w0a, rb1, re1);
+            asm volatile("" : "+v"(a0), "+v"(a1));
+            STAMP(1)
+            const float cq[4] = {__uint_as_float(uni(cv.x)), __uint_as_float(uni(cv.y)), __uint_as_float(uni(cv.z)), __uint_as_float(uni(cv.w))};
+            typedef volatile f32x2 __attribute__((address_space(3))) *wp;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if ((va >> i) & 1u) {
+                    const f32x2 q = div_by_count<2>(f32x2{a0[i], a1[i]}, cq[i]);   // the window's count: uniform
+                    *(wp)(uintptr_t)(ro2 + (uint32_t)(qw + i) * 512u) = q;
+                }
+            }
+        }
+        // stage 2: outputs of the quad B*nlead positions behind, from ring 2 (written before the previous barrier)
+        if (vb && o0 >= org) {
+            STAMP(2)
+            f32x4 a0, a1;
+            quad_windows(a0, a1, ro2, R2, q2, w0b, rb2, re2);
+            asm volatile("" : "+v"(a0), "+v"(a1));
+            STAMP(3)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if ((vb >> i) & 1u) *reinterpret_cast<f32x2 *>(out_p + (ptrdiff_t)i * mstride) = f32x2{a0[i], a1[i]};
+        }
+        STAMP(4)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's ring-2 slots are written
+        __builtin_amdgcn_s_barrier();
+        STAMP(5)
+        sb = sb == 2 ? 0 : sb + 1;
+        q1 += B; if (q1 >= R1) q1 -= R1;
+        qw += B; if (qw >= R2) qw -= R2;
+        q2 += B; if (q2 >= R2) q2 -= R2;
+        out_p += blk_m;
+    }
+#ifdef AGG_STAMP
+    if (lane == 0) {
+        for (int i = 0; i < 6; i++) atomicAdd(&g_agg_stamp[i], st[i]);
+        atomicAdd(&g_agg_stamp[7], 1ull);
+    }
+#endif
+}
+
 // Fallback without LDS (any arm cap): one wave per (position, 64 disparities), spans re-read through
 // the caches. Same addition order.
 template <bool DIV>
@@ -1183,6 +1492,7 @@ static hipError_t setup_vec() {
     set(reinterpret_cast<const void *>(&k_agg_fused<VEC, false, 0>), 160 * 1024);
     if (VEC == 2) {
         set(reinterpret_cast<const void *>(&k_agg_fused<2, true, 1>), 160 * 1024);
+        set(reinterpret_cast<const void *>(&k_agg_fused_q), 160 * 1024);
     }
     return e;
 }
@@ -1206,16 +1516,24 @@ bool aggregate_pair_fusion_supported(const Geom &g, int max_arm) {
 }
 
 // src -> (dividing pass along the axis) -> (plain pass along the same axis) -> dst; desc: that axis's pair descriptors
-void launch_aggregate_fused_pair(const float *src, float *dst, const uint4 *desc, const Geom &g, int vertical, int max_arm,
-                                 hipStream_t s) {
+// The matrix-pipe form (k_agg_fused_q) runs full 128-float ring slots whose two rings fit the LDS with quads.
+bool aggregate_quad_fusion_supported(const Geom &g, int max_arm) {
+    const int cap = quad_cap(max_arm);
+    const size_t lds = (size_t)(4 * cap + 5 * QUAD_B) * 512 + 3 * 512;
+    return g.tune.agg_mode == 2 && aggregate_pair_fusion_supported(g, max_arm) && g.Dp % 128 == 0 && lds <= 160 * 1024;
+}
+
+void launch_aggregate_fused_pair(const float *src, float *dst, const uint4 *desc, const uint4 *qdesc, const Geom &g, int vertical,
+                                 int max_arm, hipStream_t s) {
     const int vec = (g.Dp >= 128 && g.Dp % 2 == 0) ? 2 : 1;
     const int SLOT = 64 * vec;
     const int chunks = (g.Dp + SLOT - 1) / SLOT;
     const int lines = vertical ? g.W : g.H;
-    const int cap = (max_arm + 1) & ~1;                      // even (see the kernel)
     const bool fulld = g.Dp % SLOT == 0;
-    const int mode = (vec == 2 && fulld) ? g.tune.agg_mode : 0;
-    const int B = mode == 1 ? FusedShape<2, true, 1>::B : PAIR_B;
+    const bool quads = qdesc && aggregate_quad_fusion_supported(g, max_arm);
+    const int cap = quads ? quad_cap(max_arm) : (max_arm + 1) & ~1;   // a multiple of 4 / even (see the kernels)
+    const int mode = (vec == 2 && fulld) ? (g.tune.agg_mode == 2 ? 1 : g.tune.agg_mode) : 0;
+    const int B = quads ? QUAD_B : (mode == 1 ? FusedShape<2, true, 1>::B : PAIR_B);
     const int R1 = 2 * cap + 3 * B, R2 = 2 * cap + 2 * B;
     const size_t lds = (size_t)(R1 + R2) * SLOT * sizeof(float) + 3 * 512;   // + the descriptor staging buffers
     // One workgroup per CU at a time: chunks * lines workgroups run as so many rounds over the CUs, and when the last
@@ -1240,6 +1558,11 @@ void launch_aggregate_fused_pair(const float *src, float *dst, const uint4 *desc
         }
     }
     dim3 grid(chunks, nwhole + (lines - nwhole) * npieces), block(AGG_WAVES * 64);
+    if (quads) {
+        k_agg_fused_q<<<grid, dim3(QUAD_WAVES * 64), lds, s>>>(src, dst, qdesc, g.W, g.H, g.Dp, vertical, cap, R1, R2,
+                                                                quad_desc_pad(max_arm), nwhole, npieces, piece_len);
+        return;
+    }
 #define ADC_FUSED_GO(V_, F_, M_) k_agg_fused<V_, F_, M_><<<grid, block, lds, s>>>(src, dst, desc, g.W, g.H, g.Dp, vertical, cap, R1, R2, pair_desc_pad(max_arm), nwhole, npieces, piece_len)
     if (vec == 2) {
         if (!fulld) ADC_FUSED_GO(2, false, 0);

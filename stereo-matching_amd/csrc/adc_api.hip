@@ -232,6 +232,10 @@ int do_initialize(adc_handle *h, int32_t W, int32_t H, const adc_option *opt, hi
     const int arm_cap = opt->cross_L1 < 0 ? 0 : (opt->cross_L1 < 255 ? opt->cross_L1 : 255);
     const size_t n_pair_h = pair_desc_count(H, W, arm_cap), n_pair_v = pair_desc_count(W, H, arm_cap);
     A(h->pl.pair_h, n_pair_h); A(h->pl.pair_v, n_pair_v);
+    // (the quad descriptor planes of the matrix-pipe form only where that form is selected)
+    const bool want_quads = h->tune.agg_mode == 2;
+    const size_t n_quad_h = want_quads ? quad_desc_count(H, W, arm_cap) : 0, n_quad_v = want_quads ? quad_desc_count(W, H, arm_cap) : 0;
+    if (want_quads) { A(h->pl.quad_h, n_quad_h); A(h->pl.quad_v, n_quad_v); }
     A(h->vol_a, nvol); A(h->vol_b, nvol);
     A(h->lut_ad, 768); A(h->lut_cen, 68); A(h->lut_ad1, 768);
     A(h->disp_a, npx); A(h->disp_b, npx); A(h->disp_r, npx); A(h->disp_final, npx);
@@ -262,6 +266,10 @@ int do_initialize(adc_handle *h, int32_t W, int32_t H, const adc_option *opt, hi
     // the padding records in front of and behind every line of the pair descriptors stay zero for good
     HIPCHK(h, hipMemsetAsync(h->pl.pair_h, 0, n_pair_h * sizeof(uint4), s0));
     HIPCHK(h, hipMemsetAsync(h->pl.pair_v, 0, n_pair_v * sizeof(uint4), s0));
+    if (want_quads) {
+        HIPCHK(h, hipMemsetAsync(h->pl.quad_h, 0, n_quad_h * sizeof(uint4), s0));
+        HIPCHK(h, hipMemsetAsync(h->pl.quad_v, 0, n_quad_v * sizeof(uint4), s0));
+    }
 
     // exp tables of the initial cost (ADC/cost_computor.cu:186,200-203): entry = expf of the float
     // argument, taken as the correctly rounded (float)exp((double)arg).
@@ -389,6 +397,8 @@ int enqueue_match(adc_handle *h, const uint8_t *d_l, const uint8_t *d_r, float *
     const bool fuse_pairs = h->tune.agg_variant == 0 && aggregate_pair_fusion_supported(g, cap);
     // horizontal dividing passes divide by the vertical-first counts, vertical ones by the horizontal-first counts
     if (fuse_pairs) launch_pair_descriptors(pl.arms, pl.cnt_v32, pl.cnt_h32, pl.pair_h, pl.pair_v, g, cap, s);
+    const bool fuse_quads = fuse_pairs && pl.quad_h && aggregate_quad_fusion_supported(g, cap);
+    if (fuse_quads) launch_quad_descriptors(pl.arms, pl.cnt_v32, pl.cnt_h32, pl.quad_h, pl.quad_v, g, cap, s);
 
     // The initial cost volume is computed inside the first aggregation pass when that is possible; it is
     // materialised (ComputeCostCuda as a kernel of its own) when its tap is wanted or the pass cannot hold it.
@@ -417,7 +427,8 @@ int enqueue_match(adc_handle *h, const uint8_t *d_l, const uint8_t *d_r, float *
         for (int k = 0; k < 3; k++) {
             const int vertical = (k % 2) == 0;
             KMARK(ADC_KERNEL_AGGR0 + 1 + 2 * k);
-            launch_aggregate_fused_pair(cur_v, oth_v, vertical ? pl.pair_v : pl.pair_h, g, vertical, cap, s);
+            launch_aggregate_fused_pair(cur_v, oth_v, vertical ? pl.pair_v : pl.pair_h,
+                                        fuse_quads ? (vertical ? pl.quad_v : pl.quad_h) : nullptr, g, vertical, cap, s);
             KMARK(ADC_KERNEL_AGGR0 + 2 + 2 * k);   // (the pair's second pass has no launch of its own: 0 ms)
             std::swap(cur_v, oth_v);
         }

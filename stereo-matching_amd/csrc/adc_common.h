@@ -20,7 +20,7 @@ struct Tuning {
     int agg_pair = 1;       // ADC_AGG_PAIR      0: one position per wave (ring kernel)
     int cost_fuse = 1;      // ADC_COST_FUSE     0: the initial costs as a kernel of their own
     int agg_depth = 6;      // ADC_AGG_DEPTH     fill look-ahead of the ring kernel
-    int agg_mode = 1;       // ADC_AGG_MODE      0 / 1: how the fused aggregation launch fills its first ring (see k_agg_fused)
+    int agg_mode = 1;       // ADC_AGG_MODE      0 / 1: how the vector form of the fused aggregation launch fills its first ring (see k_agg_fused); 2: the matrix-pipe form where it applies (k_agg_fused_q; bit-identical, measured slower), else 1
     int agg_desc = 1;       // ADC_AGG_DESC      0: the single-pass pair kernel works its windows out from the arms even where pair descriptors exist
     int agg_split = 1;      // ADC_AGG_SPLIT     0: never cut the lines of a fused aggregation launch's last round over the CUs into pieces; n >= 2: every line in n pieces
     int wta_fused = -1;     // ADC_WTA_FUSED     0 / 1: left WTA as its own kernel / inside the last scanline pass
@@ -58,6 +58,7 @@ struct Planes {
     uint32_t *rec_rows;                 // packed colour-step flag strings of the scanline passes: 3 families x rows x 32 shifted copies
     uint32_t *rec_base;                 // the unshifted strings the copies are made from
     uint4 *pair_h, *pair_v;             // window descriptors of the position pairs of every row / column (fused aggregation)
+    uint4 *quad_h, *quad_v;             // the same for groups of four positions (two uint4 each; the matrix-pipe form of the fused launch)
 };
 
 // --- adc_pre.hip -------------------------------------------------------------------------------
@@ -99,8 +100,13 @@ bool aggregate_pair_fusion_supported(const Geom &g, int max_arm);
 size_t pair_desc_count(int lines, int len, int max_arm);   // records of one axis's descriptor plane (rows are padded)
 void launch_pair_descriptors(const uint32_t *arms, const uint32_t *cnt_for_h, const uint32_t *cnt_for_v, uint4 *desc_h,
                              uint4 *desc_v, const Geom &g, int max_arm, hipStream_t s);
-void launch_aggregate_fused_pair(const float *src, float *dst, const uint4 *desc, const Geom &g, int vertical, int max_arm,
-                                 hipStream_t s);
+void launch_aggregate_fused_pair(const float *src, float *dst, const uint4 *desc, const uint4 *qdesc, const Geom &g, int vertical,
+                                 int max_arm, hipStream_t s);
+// the matrix-pipe form of that launch (groups of four positions): its descriptor planes and when it applies
+bool aggregate_quad_fusion_supported(const Geom &g, int max_arm);
+size_t quad_desc_count(int lines, int len, int max_arm);   // uint4 elements of one axis's quad descriptor plane
+void launch_quad_descriptors(const uint32_t *arms, const uint32_t *cnt_for_h, const uint32_t *cnt_for_v, uint4 *desc_h,
+                             uint4 *desc_v, const Geom &g, int max_arm, hipStream_t s);
 
 // --- adc_scanline.hip --------------------------------------------------------------------------
 hipError_t scanline_setup_device();   // as aggregate_setup_device, for the scanline kernels

@@ -547,7 +547,7 @@ def test_fused_aggregation_pairs(pkg, orc, synth, monkeypatch, W, H, dmin, dmax,
     assert same(disp, got["disp_final"]) and same(vol, got["cost_scan"]) and same(aux, got["cost_scan_aux"])
 
 
-@pytest.mark.parametrize("mode", ["0", "1"])
+@pytest.mark.parametrize("mode", ["0", "1", "2"])
 @pytest.mark.parametrize("W,H,dmin,dmax", [(200, 120, 0, 256), (61, 150, -3, 125), (33, 35, 0, 128)])
 def test_fused_aggregation_fill_modes(pkg, orc, synth, monkeypatch, mode, W, H, dmin, dmax):
     """Full 128-float ring slots (D a multiple of 128): ring 1 of the fused aggregation launch is filled either by every

@@ -34,6 +34,15 @@ for i in range(n):
     h.match_device(dl.data_ptr(), dr.data_ptr(), out.data_ptr(), s)
 torch.cuda.synchronize()
 lib.adc_debug_agg_stamps(buf)
+if os.environ.get("AGG_STAMP_QUAD"):
+    names = ["descriptors read from the staging buffer", "stage 1: window sums (matrix pipe)", "stage 1: divide, permute, into ring 2 (+ stage-2 skipped time)",
+             "stage 2: window sums (matrix pipe)", "stage 2: permute, store", "wait + barrier"]
+    tot = float(sum(buf[i] for i in range(6)))
+    print("computing waves: %d  mean cycles per wave: %.0f" % (buf[7], tot / max(buf[7], 1)))
+    for i, nm in enumerate(names):
+        print("%-70s %6.2f %%" % (nm, 100.0 * buf[i] / tot))
+    print("loader waves: kilocycles issuing %d, waiting for fills %d (sum over all loader waves; computing waves total %d)" % (buf[6] & 0xffffffff, buf[6] >> 32, int(tot) >> 10))
+    sys.exit(0)
 names = ["descriptor DMA + early fills issued", "stage 1 (windows of ring 1, divide, into ring 2) + late fills", "stage 2 (windows of ring 2, stores)",
          "wait for the previous iteration's fills", "barrier", "ring counters + next descriptors from the staging buffer"]
 tot = float(sum(buf[i] for i in range(6)))
