@@ -912,7 +912,13 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
             int sbl = 2;
             const float *lsrc = src + lbase + (lane & 31) * 4;
             const int hi = lane >> 5;
+#ifdef AGG_STAMP
+            unsigned long long lt[3] = {0, 0, 0};
+#endif
             for (int o0 = org - B * nlead; o0 < end; o0 += B) {
+#ifdef AGG_STAMP
+                const unsigned long long t0_ = __builtin_readcyclecounter();
+#endif
                 desc_dma(2, sbl);
                 for (int w = 0; w < CW; w++) {
                     const int p = fl + 2 * w;
@@ -923,9 +929,21 @@ k_agg_fused(const float *__restrict__ src, float *__restrict__ dst, const uint4 
                         ring_fill_x4(lsrc + (ptrdiff_t)pl * mstride, ring + q * SLOT);
                     }
                 }
+#ifdef AGG_STAMP
+                const unsigned long long t1_ = __builtin_readcyclecounter();
+#endif
                 if (fl + B <= LEN) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 + CW) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef AGG_STAMP
+                const unsigned long long t2_ = __builtin_readcyclecounter();
+#endif
                 __builtin_amdgcn_s_barrier();
+#ifdef AGG_STAMP
+                lt[0] += t1_ - t0_; lt[1] += t2_ - t1_; lt[2] += __builtin_readcyclecounter() - t2_;
+                if (o0 + B >= end && lane == 0) {   // (diagnostic build: the loader's issue / fill wait / barrier wait, in 1024 cycles)
+                    atomicAdd(&g_agg_stamp[6], (lt[0] >> 10) | ((lt[1] >> 10) << 20) | ((lt[2] >> 10) << 40));
+                }
+#endif
                 fl += B;
                 ql += B; if (ql >= R1) ql -= R1;
                 sbl = sbl == 2 ? 0 : sbl + 1;      // (the order the computing waves read them in)

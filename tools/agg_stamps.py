@@ -49,3 +49,7 @@ tot = float(sum(buf[i] for i in range(6)))
 print("waves: %d  mean cycles per wave: %.0f (s_memtime ticks)" % (buf[7], tot / max(buf[7], 1)))
 for i, nm in enumerate(names):
     print("%-52s %6.2f %%" % (nm, 100.0 * buf[i] / tot))
+li, lw, lb = buf[6] & 0xfffff, (buf[6] >> 20) & 0xfffff, buf[6] >> 40
+if li + lw + lb:
+    print("loader waves: issuing %.1f %%, waiting for fills %.1f %%, at the barrier %.1f %% of their time"
+          % (100.0 * li / (li + lw + lb), 100.0 * lw / (li + lw + lb), 100.0 * lb / (li + lw + lb)))
