@@ -134,7 +134,10 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # Under a launcher (WORLD_SIZE set) the process group is always formed, also with a single rank: the one-rank run is
+    # then the same code as the N-rank run (RCCL init on the device, barrier, max-over-ranks on a device tensor).
+    use_dist = env_world is not None
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
     if not torch.cuda.is_available():
@@ -143,7 +146,9 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    backend = None
+    if use_dist:
+        backend = "gloo" if args.rehearse else "nccl"
         if args.rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -169,7 +174,7 @@ def main():
 
     batch = importlib.import_module("stereo-matching_amd.batch")
     elapsed = batch.timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize,
-                                dist if world > 1 else None, None if args.rehearse else dev)
+                                dist if use_dist else None, None if args.rehearse else dev)
 
     valid_fraction = float(torch.isfinite(d_out).float().mean().item())
 
@@ -222,7 +227,7 @@ def main():
         opt = pkg.ADCensusOption(max_disparity=D)
         pkg.match_batch(lefts[:4], rights[:4], opt, [local_rank], handles=[h], out=dst[:4])      # second staging set allocated
         b_elapsed = batch.timed_steps(lambda i: pkg.match_batch(lefts, rights, opt, [local_rank], handles=[h], out=dst), 1, 0,
-                                      torch.cuda.synchronize, dist if world > 1 else None, None if args.rehearse else dev)
+                                      torch.cuda.synchronize, dist if use_dist else None, None if args.rehearse else dev)
         batch_leg = {"pairs_per_gpu": n, "distinct_pairs": n_distinct, "n_gpus": world, "seconds": b_elapsed,
                      "ms_per_frame": b_elapsed / n * 1e3, "pairs_per_s": world * n / b_elapsed,
                      "value": world * n * W * H * D * 1e-6 / b_elapsed, "unit": "Mpix*disp/s",
@@ -297,6 +302,7 @@ def main():
             "value_pcie": t_match["value"] if t_match else None,
             "unit": "Mpix*disp/s",
             "n_gpus": world,
+            "dist_backend": backend,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_frame,
@@ -372,7 +378,7 @@ def main():
             out["c4"] = c4_leg(pkg, synth, torch, dev, local_rank)
         print(json.dumps(out), flush=True)
     h.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
